@@ -1,0 +1,180 @@
+/*
+ * spdm.h -- C ABI of libspdm_hip.so: the MI355X (gfx950) denoising hot path of
+ * rafaelsoStanford/State_Policy_DiffusionModel.
+ *
+ * The reference has no FFI/plugin registry: its boundary for this path is the
+ * Python object protocol.  Each entry point below names the
+ * reference call it stands behind; the Python host mirror lives in
+ * state_policy_diffusionmodel_amd/{engine,diffusion,schedulers}.py and binds
+ * these symbols with ctypes (INTEGRATION.md shows the stub a reference
+ * maintainer would add).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch / HIP types in signatures
+ *    (`stream` is a hipStream_t passed as void*; NULL = the null stream and the
+ *    call synchronises before returning, matching the reference's blocking
+ *    semantics).
+ *  - `d_` pointers are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm
+ *    tensors' data_ptr()), `h_` pointers are HOST pointers.
+ *  - Tensors at the boundary use the reference's own layouts: trajectories
+ *    (B,1,H,D) contiguous fp32 == (B,H,D); cond (B,1,obs_h,obs_dim) == (B,cond_dim).
+ *  - Every function returns 0 on success or a negative spdm_status; the text of
+ *    the last error is available from spdm_last_error().  Nothing throws across
+ *    the ABI and nothing calls exit().
+ *  - One handle = one device = one in-flight call (not re-entrant per handle;
+ *    distinct handles are independent).
+ */
+#ifndef SPDM_H
+#define SPDM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPDM_NAME_MAX 64
+#define SPDM_ABI_VERSION 1
+
+typedef enum {
+    SPDM_OK = 0,
+    SPDM_ERR_INVALID = -1,      /* bad argument / shape */
+    SPDM_ERR_HIP = -2,          /* a HIP runtime call failed */
+    SPDM_ERR_STATE = -3,        /* call order (weights/schedule not set, ...) */
+    SPDM_ERR_MISSING = -4,      /* tensor name not found in the index */
+    SPDM_ERR_NOMEM = -5
+} spdm_status;
+
+typedef enum { SPDM_DDPM = 0, SPDM_DDIM = 1 } spdm_scheduler_kind;
+
+typedef struct spdm_handle spdm_handle;
+
+/* Shape of one noise predictor instance.  Mirrors the constructor arguments at
+ * models/diffusion_ddpm.py:76-82 (UNet_Film(in=1, out=1, noise_steps,
+ * global_cond_dim=observation_dim*obs_horizon, time_dim=256)) plus the trajectory
+ * geometry sample() uses (pred_horizon + inpaint_horizon rows of prediction_dim,
+ * models/diffusion_ddpm.py:252). */
+typedef struct {
+    int32_t horizon;              /* H: rows of x_t (unpadded)                      */
+    int32_t state_dim;            /* D: columns of x_t (unpadded), 1..8             */
+    int32_t cond_dim;             /* obs_horizon * observation_dim (flattened y)    */
+    int32_t time_dim;             /* sinusoidal embedding width (256)               */
+    int32_t attention;            /* 1: UNet_Film, 0: UNet_Film_noAttention         */
+    int32_t max_batch;            /* workspace is sized for this many trajectories  */
+    int32_t device;               /* HIP device ordinal                             */
+    int32_t num_train_timesteps;  /* rows of the time-embedding table (t < this)    */
+    int32_t flags;                /* SPDM_FLAG_*                                    */
+} spdm_config;
+
+#define SPDM_FLAG_DEBUG_KEEP 1    /* keep every intermediate alive for spdm_debug_tensor */
+
+/* One entry per tensor of the reference state_dict (names exactly as
+ * UNet_Film.state_dict() gives them, e.g. "down1.cond_encoder.2.weight"),
+ * torch-native layouts (conv: (Cout,Cin,3,3); linear: (out,in)). */
+typedef struct {
+    char     name[SPDM_NAME_MAX];
+    uint64_t offset;              /* in floats, into the blob */
+    uint64_t numel;
+    int32_t  ndim;
+    int32_t  shape[4];
+} spdm_tensor_index;
+
+int  spdm_abi_version(void);
+const char* spdm_last_error(void);
+
+/* Replaces: Diffusion_DDPM.__init__'s construction of self.noise_estimator
+ * (models/diffusion_ddpm.py:76-82).  Allocates weights + workspace on `device`. */
+int  spdm_create(const spdm_config* cfg, spdm_handle** out);
+void spdm_destroy(spdm_handle* h);
+
+/* Replaces: load_state_dict of the `noise_estimator.*` tensors
+ * (generate.py:25-27 -> Lightning load_from_checkpoint).  `h_blob` is a HOST
+ * array; the library re-lays the weights out for its kernels and uploads them. */
+int  spdm_load_weights(spdm_handle* h, const float* h_blob, size_t n_floats,
+                       const spdm_tensor_index* h_index, int32_t n_index);
+
+/* Optional: overwrite the sinusoidal table pos_encoding(t) for t = 0..T-1
+ * (models/Unet_FiLmLayer.py:266-274), (T, time_dim) fp32 on the host.  By
+ * default the library computes it itself in fp32; the Python host passes
+ * torch's own values so that the table is bit-identical to the reference's. */
+int  spdm_set_time_table(spdm_handle* h, const float* h_table, int32_t T);
+
+/* Replaces: DDPMScheduler(...)/DDIMScheduler(...) construction +
+ * set_timesteps(n) (models/diffusion_ddpm.py:65-70,268; generate.py:28-35).
+ * Linear betas in [beta_start, beta_end], epsilon prediction, no clipping,
+ * fixed_small variance / eta = 0. */
+int  spdm_set_schedule(spdm_handle* h, int32_t kind, int32_t num_train_timesteps,
+                       int32_t num_inference_steps, float beta_start, float beta_end);
+
+/* Same, from caller-computed tables (a caller-assigned scheduler object):
+ * h_timesteps[n_steps] in loop order, h_coef[n_steps][6] =
+ *   { sqrt(1-abar_t), sqrt(abar_t), k_x0, k_x, k_eps, k_noise } with
+ *   x0   = (x - c0*eps) / c1
+ *   prev = k_x0*x0 + k_x*x [+ k_noise*z]   (DDPM)
+ *   prev = k_x0*x0 + k_eps*eps              (DDIM, eta = 0)                       */
+int  spdm_set_schedule_tables(spdm_handle* h, int32_t kind, int32_t n_steps,
+                              const int32_t* h_timesteps, const float* h_coef);
+
+/* Pure host helper (no GPU needed): the tables spdm_set_schedule would build. */
+int  spdm_schedule_tables(int32_t kind, int32_t num_train_timesteps, int32_t num_inference_steps,
+                          float beta_start, float beta_end,
+                          int32_t* h_timesteps_out, float* h_coef_out /* [n][6] */);
+
+/* Replaces: self.noise_estimator(x_t, torch.tensor([t]), obs_cond)
+ * (models/diffusion_ddpm.py:272 -> UNet_Film.forward, models/Unet_FiLmLayer.py:277-312).
+ * d_x (B,H,D), h_t[t_count] with t_count == 1 (broadcast) or B, d_cond (B,cond_dim),
+ * d_eps (B,H,D).  cond may be NULL (no FiLM, `y=None`). */
+int  spdm_unet_forward(spdm_handle* h, int32_t B, const float* d_x, const int32_t* h_t,
+                       int32_t t_count, const float* d_cond, float* d_eps, void* stream);
+
+/* Replaces: the body of Diffusion_DDPM.sample / Diffusion_DDIM.sample after the
+ * conditioning vectors are built (models/diffusion_ddpm.py:252-277,
+ * models/diffusion_ddim.py:52-74): for t in timesteps: eps = unet(x,t,cond);
+ * x = scheduler.step(eps,t,x).prev_sample; x[:, :, :inp_h, :] = inpaint.
+ *
+ *  d_cond     (B,cond_dim)
+ *  d_inpaint  (B,inp_h,D) if inpaint_per_sample else (inp_h,D) broadcast; NULL/inp_h=0: none
+ *  d_xT       (B,H,D) initial sample (the reference draws it uniform, ddpm.py:252)
+ *  d_noise    (n_steps,B,H,D) pre-drawn N(0,1) (row i used by loop iteration i when t>0),
+ *             or NULL: device Philox4x32-10 stream keyed by (seed, sample_offset+b, i)
+ *  d_out      (B,H,D) final x_0
+ *  d_history  NULL or (n_steps+1,B,H,D): x_T followed by every iterate (option='sample_history')
+ */
+int  spdm_sample(spdm_handle* h, int32_t B, const float* d_cond,
+                 const float* d_inpaint, int32_t inp_h, int32_t inpaint_per_sample,
+                 const float* d_xT, const float* d_noise, uint64_t seed, uint64_t sample_offset,
+                 float* d_out, float* d_history, void* stream);
+
+/* The same loop in three pieces, so a caller (bench.py) can time an exact range
+ * of denoise steps: begin() hoists the step-invariant FiLM projections and
+ * loads x_T; run() executes loop iterations [step_begin, step_end); result()
+ * copies the current iterate out. */
+int  spdm_sample_begin(spdm_handle* h, int32_t B, const float* d_cond,
+                       const float* d_inpaint, int32_t inp_h, int32_t inpaint_per_sample,
+                       const float* d_xT, const float* d_noise, uint64_t seed,
+                       uint64_t sample_offset, float* d_history, void* stream);
+int  spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_end, void* stream);
+int  spdm_sample_result(spdm_handle* h, float* d_out, void* stream);
+
+/* Introspection for tests: copy a named intermediate of the LAST
+ * spdm_unet_forward (handle created with SPDM_FLAG_DEBUG_KEEP) to d_out in
+ * channels-last (B, H_l*W_l, C) order; shape_out = {B, H_l, W_l, C}.
+ * Names: x1 d1 x2 d2 x3 d3 x4 x5 u1 a4 u2 a5 u3 a6. */
+int  spdm_debug_tensor(spdm_handle* h, const char* name, float* d_out, size_t cap_floats,
+                       int32_t shape_out[4]);
+
+/* Workspace bytes currently reserved on the device (weights + arena). */
+size_t spdm_device_bytes(const spdm_handle* h);
+
+/* Device time of the dominant kernel class, measured with HIP events on the
+ * launch stream: when enabled, every conv3x3 implicit-GEMM launch is bracketed
+ * by events; spdm_profile_read returns launches, total ms and total FLOPs
+ * since the last reset.  For bench.py's roofline leg only (adds sync points). */
+int  spdm_profile_enable(spdm_handle* h, int32_t on);
+int  spdm_profile_read(spdm_handle* h, int64_t* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPDM_H */

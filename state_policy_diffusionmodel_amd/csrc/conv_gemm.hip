@@ -1,0 +1,386 @@
+// conv_gemm.hip -- the dominant kernel: 3x3 convolution / Linear as an implicit GEMM on the
+// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 157 TFLOP/s chip peak).
+//
+// Replaces, on the reference's path: every nn.Conv2d(k=3, padding=1, bias=False) of
+// DoubleConvolution (models/Unet_FiLmLayer.py:101-103) together with the GroupNorm(1,C) -> GELU
+// that precedes it (:112-113, fused as the load PROLOGUE) and the GroupNorm statistics of what it
+// produces (:112/:115, fused as the EPILOGUE); and, with one tap, the Linear layers of
+// SelfAttention (:60-67), emb_layer (:136-142) and cond_encoder (:149-154).
+//
+//   out[m][n] = sum_tap sum_ci  f(in[m + shift(tap)][ci]) * w[tap][n][ci]          m = b*HW + h*W + w
+//
+// Tiling (one workgroup = 4 wave64, one 128 x N_T output tile, N_T = 64 or 128):
+//   * K is walked in chunks of 32 input channels.  Per chunk the workgroup stages ONE halo'd slab
+//     of the input -- rows [m0-(W+1), m0+128+(W+1)) x 32 channels -- into LDS, applying f (GroupNorm
+//     affine from the producer's fp64 partial sums, optional erf-GELU) once; the 9 taps are 9
+//     shifted views of that slab, so the input is read from L2/HBM once per chunk, not 9 times.
+//     Out-of-image taps (zero padding, sample boundaries) are masked per lane at fragment read.
+//   * per (chunk, tap) the 128 x 32 weight slab w[tap][n0..][k0..] is staged to LDS.
+//   * both slabs are double-buffered through registers: global loads for the next slab are issued
+//     before the MFMA block of the current one and written to LDS after it; one barrier per tap.
+//   * LDS rows are padded 32 -> 36 floats: a half-wave's 32 lanes then read 32 distinct rows with
+//     ds_read_b128 conflict-free (row stride 144 B = 9 x 16 B, 9 odd).
+//   * each lane fetches 4 consecutive k of its row (one ds_read_b128) and feeds them to 4 MFMAs;
+//     lane half h supplies k = 8g + 4h + s in step s, identically for A and B, so the reduction
+//     order is a fixed permutation of k.
+//   * epilogue: GroupNorm partial sums (fp32 per 4-row unit -> fp64 per sample, fixed order) or
+//     bias / GELU / residual for Linear layers; rows on registers, channels on lanes -> each store
+//     instruction writes two full 128-byte lines.
+//   * blockIdx is remapped so that the n-tiles of one m-tile run on the same XCD (shared L2).
+#include "device_utils.h"
+
+namespace spdm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 32;    // channels per K chunk
+constexpr int LDK = 36;   // padded LDS row length (floats)
+
+template <bool HALO, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
+    constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
+    constexpr int APASS = HALO ? (M_T + 18 + 31) / 32 : M_T / 32;   // halo <= 9 rows each side (W <= 8)
+    constexpr int WPASS = N_T / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, kh = lane >> 5;
+    const int HW = a.HW, W = a.W, H = a.H, M = a.M, K = a.K, N = a.N, taps = a.taps;
+    const int halo = HALO ? (W + 1) : 0;
+    const int QA = M_T + 2 * halo;
+    const int NSP = (QA + 4) & ~3;
+
+    // ---- tile of this workgroup (XCD-aware, bijective remap) ----
+    const int n_ntiles = N / N_T;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int mtile = logical / n_ntiles, ntile = logical - mtile * n_ntiles;
+    const int m0 = mtile * M_T, n0 = ntile * N_T;
+
+    float* Abuf = smem;                       // [2][QA][LDK]
+    float* Wbuf = Abuf + 2 * QA * LDK;        // [2][N_T][LDK]
+    float* smean = Wbuf + 2 * N_T * LDK;      // [NSP]
+    float* srstd = smean + NSP;               // [NSP]
+
+    // ---- prologue statistics of the samples this slab touches ----
+    const bool pro = (a.pro != PRO_NONE);
+    const bool pro_gelu = (a.pro == PRO_GN_GELU);
+    int bh_first = 0;
+    if (pro) {
+        const int lo = max(m0 - halo, 0), hi = min(m0 + M_T + halo, M) - 1;
+        bh_first = lo / HW;
+        const int bh_last = hi / HW;
+        for (int t = tid; t <= bh_last - bh_first; t += 256) {
+            float mean, rstd;
+            sample_mean_rstd(a.pro_stats, bh_first + t, mean, rstd);
+            smean[t] = mean;
+            srstd[t] = rstd;
+        }
+        __syncthreads();
+    }
+
+    // ---- per-thread staging assignment: 8 threads x float4 cover one 32-channel row ----
+    const int srow_t = tid >> 3, c4 = tid & 7;
+    bool aval[APASS];
+    const float* aptr[APASS];
+    float amean[APASS], arstd[APASS];
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+        const int q = p * 32 + srow_t;
+        const int m = m0 - halo + q;
+        const bool v = (q < QA) && (m >= 0) && (m < M);
+        aval[p] = v;
+        aptr[p] = a.src + (size_t)(v ? m : 0) * a.src_ld + c4 * 4;
+        amean[p] = 0.f;
+        arstd[p] = 1.f;
+        if (pro && v) {
+            const int b = m / HW;
+            amean[p] = smean[b - bh_first];
+            arstd[p] = srstd[b - bh_first];
+        }
+    }
+    const float* wptr = a.wgt + (size_t)(n0 + srow_t) * K + c4 * 4;   // + (tap*N + p*32)*K + chunk*32
+
+    // ---- per-lane fragment rows and tap masks ----
+    int aoff[MT], boff[NT];
+    unsigned amask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = wm * MT * 32 + mt * 32 + li;
+        aoff[mt] = (r + halo) * LDK + kh * 4;
+        unsigned mask = 0;
+        if (HALO) {
+            const int m = m0 + r;
+            if (m < M) {
+                const int p = m % HW;
+                const int h = p / W, w = p - h * W;
+                for (int t = 0; t < taps; ++t) {
+                    const int dh = (taps == 9) ? t / 3 - 1 : t - 1;
+                    const int dw = (taps == 9) ? t % 3 - 1 : 0;
+                    const bool ok = (h + dh >= 0) && (h + dh < H) && (w + dw >= 0) && (w + dw < W);
+                    mask |= (ok ? 1u : 0u) << t;
+                }
+            }
+        }
+        amask[mt] = mask;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = (wn * NT * 32 + nt * 32 + li) * LDK + kh * 4;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    float4 areg[APASS], wreg[WPASS];
+
+    auto load_A = [&](int chunk) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            areg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (aval[p]) areg[p] = *reinterpret_cast<const float4*>(aptr[p] + chunk * CK);
+        }
+    };
+    auto store_A = [&](int chunk, int buf) {
+        float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pro) {
+            g4 = *reinterpret_cast<const float4*>(a.pro_gamma + chunk * CK + c4 * 4);
+            b4 = *reinterpret_cast<const float4*>(a.pro_beta + chunk * CK + c4 * 4);
+        }
+        float* dstb = Abuf + buf * QA * LDK + c4 * 4;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const int q = p * 32 + srow_t;
+            float4 v = areg[p];
+            if (pro && aval[p]) {
+                const float rs = arstd[p], mu = amean[p];
+                float sx = rs * g4.x, sy = rs * g4.y, sz = rs * g4.z, sw = rs * g4.w;
+                v.x = (v.x - mu) * sx + b4.x;
+                v.y = (v.y - mu) * sy + b4.y;
+                v.z = (v.z - mu) * sz + b4.z;
+                v.w = (v.w - mu) * sw + b4.w;
+                if (pro_gelu) {
+                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                }
+            }
+            if (q < QA) *reinterpret_cast<float4*>(dstb + q * LDK) = v;
+        }
+    };
+    auto load_W = [&](int chunk, int tap) {
+        const float* base = wptr + (size_t)tap * N * K + chunk * CK;
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) wreg[p] = *reinterpret_cast<const float4*>(base + (size_t)p * 32 * K);
+    };
+    auto store_W = [&](int buf) {
+        float* dstb = Wbuf + buf * N_T * LDK + srow_t * LDK + c4 * 4;
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) *reinterpret_cast<float4*>(dstb + p * 32 * LDK) = wreg[p];
+    };
+
+    const int nchunks = K / CK;
+    const int niter = nchunks * taps;
+
+    load_A(0);
+    load_W(0, 0);
+    store_A(0, 0);
+    store_W(0);
+    __syncthreads();
+
+    int chunk = 0, tap = 0;
+    for (int it = 0; it < niter; ++it) {
+        // next (chunk, tap)
+        int ntap = tap + 1, nchunk = chunk;
+        if (ntap == taps) { ntap = 0; nchunk = chunk + 1; }
+        const bool have_next = (it + 1 < niter);
+        const bool next_A = have_next && (ntap == 0);
+        if (have_next) load_W(nchunk, ntap);
+        if (next_A) load_A(nchunk);
+
+        // ---- MFMA block on Abuf[chunk&1], Wbuf[it&1] ----
+        const float* Ab = Abuf + (chunk & 1) * QA * LDK;
+        const float* Wb = Wbuf + (it & 1) * N_T * LDK;
+        int shift = 0;
+        if (HALO) {
+            const int dh = (taps == 9) ? tap / 3 - 1 : tap - 1;
+            const int dw = (taps == 9) ? tap % 3 - 1 : 0;
+            shift = (dh * W + dw) * LDK;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                av[mt] = *reinterpret_cast<const float4*>(Ab + aoff[mt] + shift + g * 8);
+                if (HALO && !((amask[mt] >> tap) & 1u)) av[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(Wb + boff[nt] + g * 8);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+
+        if (have_next) store_W((it + 1) & 1);
+        if (next_A) store_A(nchunk, nchunk & 1);
+        __syncthreads();
+        tap = ntap;
+        chunk = nchunk;
+    }
+
+    // ---- epilogue ----
+    const int row_base = m0 + wm * MT * 32 + 4 * kh;     // + mt*32 + (r&3) + 8*(r>>2)
+    const int col_base = n0 + wn * NT * 32 + li;         // + nt*32
+
+    if (a.epi == EPI_STATS) {
+        float* srow = Abuf;                              // [M_T / unit][WN][2], aliases the A slabs
+        const bool unit4 = (HW & 3) == 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = wm * MT * 32 + mt * 32 + 8 * g + 4 * kh;     // tile-local row of register 4g
+                if (unit4) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = acc[mt][nt][4 * g + j];
+                            s1 += v;
+                            s2 += v * v;
+                        }
+                    s1 = half_sum(s1);
+                    s2 = half_sum(s2);
+                    if (li == 0) {
+                        srow[((r0 >> 2) * WN + wn) * 2] = s1;
+                        srow[((r0 >> 2) * WN + wn) * 2 + 1] = s2;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const float v = acc[mt][nt][4 * g + j];
+                            s1 += v;
+                            s2 += v * v;
+                        }
+                        s1 = half_sum(s1);
+                        s2 = half_sum(s2);
+                        if (li == 0) {
+                            srow[((r0 + j) * WN + wn) * 2] = s1;
+                            srow[((r0 + j) * WN + wn) * 2 + 1] = s2;
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+        const int t_lo = m0, t_hi = min(m0 + M_T, M);
+        if (t_hi > t_lo) {
+            const int b_first = t_lo / HW, b_last = (t_hi - 1) / HW;
+            const int ush = unit4 ? 2 : 0;
+            for (int t = tid; t <= b_last - b_first; t += 256) {
+                const int b = b_first + t;
+                const int r_lo = max(b * HW, t_lo) - m0, r_hi = min((b + 1) * HW, t_hi) - m0;
+                double s1 = 0.0, s2 = 0.0;
+                for (int u = r_lo >> ush; u < ((r_hi + (unit4 ? 3 : 0)) >> ush); ++u)
+                    for (int w2 = 0; w2 < WN; ++w2) {
+                        s1 += (double)srow[(u * WN + w2) * 2];
+                        s2 += (double)srow[(u * WN + w2) * 2 + 1];
+                    }
+                const int slot = (mtile - (b * HW) / M_T) * n_ntiles + ntile;
+                double* o = a.epi_stats + ((size_t)b * epi_slots + slot) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col_base + nt * 32;
+            float bias = 0.f;
+            if (a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID) bias = a.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < M) {
+                    float v = acc[mt][nt][r] + bias;
+                    if (a.epi == EPI_BIAS_GELU) v = gelu_erf(v);
+                    if (a.epi == EPI_BIAS_RESID) v += a.resid[(size_t)row * a.resid_ld + col];
+                    a.dst[(size_t)row * a.dst_ld + col] = v;
+                }
+            }
+        }
+}
+
+// -------------------------------------------------------------------------------------------------
+GemmGeom gemm_geometry(int M, int N, int HW) {
+    GemmGeom g;
+    g.m_tile = 128;
+    g.n_tile = (N % 128 == 0) ? 128 : 64;
+    g.n_tiles = N / g.n_tile;
+    g.slots = stats_slots(HW, g.m_tile, g.n_tiles);
+    (void)M;
+    return g;
+}
+
+double gemm_flops(const GemmArgs& a) { return 2.0 * (double)a.M * (double)a.N * (double)a.K * (double)a.taps; }
+
+template <bool HALO, int WM, int WN, int MT, int NT>
+static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
+    constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
+    const int halo = HALO ? a.W + 1 : 0;
+    const int QA = M_T + 2 * halo;
+    const int NSP = (QA + 4) & ~3;
+    const size_t lds = (size_t)(2 * QA * LDK + 2 * N_T * LDK + 2 * NSP) * sizeof(float);
+    auto kern = conv_gemm_kernel<HALO, WM, WN, MT, NT>;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        lds_set = 160 * 1024;
+    }
+    const int n_mtiles = (a.M + M_T - 1) / M_T;
+    const int grid = n_mtiles * g.n_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, g.slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    // shape contract of the kernel -- checked on the host so that a bad plan can never fault the GPU
+    if (a.M <= 0 || a.K <= 0 || a.N <= 0) return hipErrorInvalidValue;
+    if (a.K % CK != 0 || a.N % 64 != 0) return hipErrorInvalidValue;
+    if (a.src_ld % 4 != 0 || a.src_ld < a.K) return hipErrorInvalidValue;
+    if (!(a.taps == 1 || a.taps == 3 || a.taps == 9)) return hipErrorInvalidValue;
+    if (a.taps != 1 && (a.W < 1 || a.W > 8 || a.H < 1 || a.HW != a.H * a.W || a.M % a.HW != 0)) return hipErrorInvalidValue;
+    if (a.taps == 3 && a.W != 1) return hipErrorInvalidValue;
+    if (a.HW < 1) return hipErrorInvalidValue;
+    if (a.pro != PRO_NONE && (a.pro_stats.p == nullptr || a.pro_gamma == nullptr || a.pro_beta == nullptr ||
+                              a.pro_stats.HW != a.HW)) return hipErrorInvalidValue;
+    if (a.epi == EPI_STATS && a.epi_stats == nullptr) return hipErrorInvalidValue;
+    if ((a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID) && a.bias == nullptr) return hipErrorInvalidValue;
+    if (a.epi == EPI_BIAS_RESID && a.resid == nullptr) return hipErrorInvalidValue;
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW);
+    if (a.taps == 1) {
+        if (g.n_tile == 128) return launch_cfg<false, 2, 2, 2, 2>(a, g, s);
+        return launch_cfg<false, 2, 2, 2, 1>(a, g, s);
+    }
+    if (g.n_tile == 128) return launch_cfg<true, 2, 2, 2, 2>(a, g, s);
+    return launch_cfg<true, 2, 2, 2, 1>(a, g, s);
+}
+
+}  // namespace spdm

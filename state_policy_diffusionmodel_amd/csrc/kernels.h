@@ -1,0 +1,100 @@
+// kernels.h -- launch-side declarations of the hand-written gfx950 kernels.
+//
+// Activation layout everywhere: CHANNELS-LAST  act[b][p][c]  with p = h*W_l + w
+// (the reference's NCHW "(B,C,H,W) image", models/Unet_FiLmLayer.py:286, viewed
+// as tokens x channels -- which is also the (B,L,C) view its attention blocks
+// take at :74).  A 3x3 convolution is then an implicit GEMM
+//     out[m][n] = sum_{tap,ci} in[m + shift(tap)][ci] * w[tap][n][ci],   m = b*HW + p
+// and a Linear layer is the same GEMM with one tap.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spdm {
+
+// GroupNorm(1,C) statistics are produced by the kernel that writes a tensor, as
+// per-(sample, tile) partial sums in fp64:  stats[(b*slots + slot)*2 + {0,1}] =
+// {sum x, sum x^2}.  Slot of the partial that tile (mt, nt) contributes to
+// sample b:  (mt - (b*HW)/m_tile) * n_tiles + nt.  Consumers add the valid
+// slots in a fixed order, so results are run-to-run deterministic.
+struct StatsRef {
+    const double* p;     // nullptr: no normalisation
+    int slots;           // slots per sample
+    int m_tile;          // rows per producer tile
+    int n_tiles;         // producer tiles along channels
+    int HW;              // rows per sample of the normalised tensor
+    double inv_count;    // 1 / (C * HW)
+};
+
+__host__ __device__ inline int stats_slots(int HW, int m_tile, int n_tiles) {
+    return ((HW + m_tile - 2) / m_tile + 1) * n_tiles;
+}
+
+enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_GELU = 2 };
+enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RESID = 3, EPI_PLAIN = 4 };
+
+struct GemmArgs {
+    const float* src;  int src_ld;     // [M][src_ld], K valid channels
+    const float* wgt;                  // [taps][N][K]  (k contiguous)
+    float* dst;        int dst_ld;
+    int M, K, N;
+    int taps;                          // 1, 3 (vertical taps, W == 1) or 9
+    int H, W, HW;                      // spatial dims of this level
+    int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
+    int epi;  double* epi_stats;   const float* bias;  const float* resid;  int resid_ld;
+};
+
+// geometry of the stats the GEMM writes (EPI_STATS)
+struct GemmGeom { int m_tile, n_tile, n_tiles, slots; };
+GemmGeom gemm_geometry(int M, int N, int HW);
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+double gemm_flops(const GemmArgs& a);
+
+// ---- streaming / small kernels (elementwise.hip) -------------------------------------------
+// first conv, Cin = 1, fused zero-padding of the (H0, D) trajectory to (Hp, Wp)
+hipError_t launch_conv_in(const float* x, const float* w /*[9][64]*/, float* dst, double* stats,
+                          int B, int H0, int D, int Hp, int Wp, int lh, int lw, hipStream_t s);
+
+struct AffineSrc {               // a tensor + the per-(sample,channel) affine that finishes it
+    const float* x; int C;       // channels-last [B][HW][C]
+    StatsRef st; const float* gamma; const float* beta;   // GroupNorm part (st.p may be null)
+};
+// MaxPool2d(2) of affine(src):  (B, H*W, C) -> (B, H/2*W/2, C)
+hipError_t launch_pool(const AffineSrc& src, float* dst, int B, int H, int W, hipStream_t s);
+// cat([bilinear_x2_align_corners(affine(up)), affine(skip)], channel)
+hipError_t launch_upcat(const AffineSrc& up, const AffineSrc& skip, float* dst, int B, int Hin, int Win,
+                        hipStream_t s);
+// block tail: y = scale * (GN(x) + temb[t]) + bias   (FiLM; film == nullptr: y = GN(x) + temb)
+hipError_t launch_film_apply(const AffineSrc& src, const float* temb_table /*[T][C]*/, const int* t_dev,
+                             int t_count, const float* film /*[B][2C] or null*/, float* dst, int B, int HW,
+                             hipStream_t s);
+// plain GN apply (materialise): y = GN(x)
+hipError_t launch_gn_apply(const AffineSrc& src, float* dst, int B, int HW, hipStream_t s);
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int C,
+                            hipStream_t s);
+hipError_t launch_mish_pad(const float* cond, float* dst, int B, int cond_dim, int Kp, hipStream_t s);
+hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t s);
+
+struct StepArgs {
+    const float* feat;            // (B, Hp*Wp, 64) channels-last
+    const float* w; float bias;   // outc 1x1 conv
+    float* x;                     // (B, H0, D) current iterate, updated in place
+    float* eps_out;               // non-null: only write eps (spdm_unet_forward)
+    const float* coef;            // device [n_steps][6]
+    const int* step_dev;          // device scalar: loop iteration
+    int kind;
+    const float* noise;           // (n_steps, B, H0, D) or null
+    unsigned long long seed, sample_offset;
+    const float* inpaint; int inp_h; int inpaint_per_sample;
+    float* history;               // (n_steps+1, B, H0, D) or null
+    int B, H0, D, Hp, Wp, lh, lw;
+};
+hipError_t launch_out_step(const StepArgs& a, hipStream_t s);
+hipError_t launch_advance(int* step_dev, int* t_dev, const int* timesteps_dev, int n_steps, hipStream_t s);
+hipError_t launch_set_step(int* step_dev, int* t_dev, const int* timesteps_dev, int n_steps, int i, hipStream_t s);
+
+// ---- attention core (attention.hip): softmax(q k^T / sqrt d) v per (sample, head) -----------
+hipError_t launch_attention(const float* qkv /*[B*L][3C]*/, float* out /*[B*L][C]*/, int B, int L, int C,
+                            int heads, hipStream_t s);
+
+}  // namespace spdm

@@ -1,0 +1,975 @@
+// spdm_api.hip -- host side of libspdm_hip.so: the C ABI of include/spdm.h, the weight re-layout,
+// the workspace arena and the launch plan of one U-Net evaluation / one denoise step.
+//
+// The plan follows UNet_Film.forward (models/Unet_FiLmLayer.py:277-312) block by block; every
+// launch_* call names the kernel that replaces the torch ops of that line range (kernels.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/spdm.h"
+#include "kernels.h"
+
+using namespace spdm;
+
+// -------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(SPDM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define SPDM_TRY(expr)              \
+    do {                            \
+        int _r = (expr);            \
+        if (_r != SPDM_OK) return _r; \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// -------------------------------------------------------------------------------------------------
+// Workspace arena: first-fit free list over one hipMalloc'd slab.  The plan allocates and releases
+// in a deterministic order, so a dry run with max_batch at create() sizes the slab exactly.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, peak = 0;
+    bool dry = false, keep = false;
+    struct Blk { size_t off, size; bool free; };
+    std::vector<Blk> blks;
+    void reset() {
+        blks.clear();
+        blks.push_back({0, (size_t)1 << 60, true});
+    }
+    bool alloc(size_t bytes, size_t* off) {
+        bytes = align_up(std::max<size_t>(bytes, 256), 256);
+        for (size_t i = 0; i < blks.size(); ++i) {
+            if (blks[i].free && blks[i].size >= bytes) {
+                const size_t o = blks[i].off, rest = blks[i].size - bytes;
+                blks[i].size = bytes;
+                blks[i].free = false;
+                if (rest) blks.insert(blks.begin() + i + 1, Blk{o + bytes, rest, true});
+                peak = std::max(peak, o + bytes);
+                if (!dry && o + bytes > cap) return false;
+                *off = o;
+                return true;
+            }
+        }
+        return false;
+    }
+    void release(size_t off) {
+        if (keep) return;
+        for (size_t i = 0; i < blks.size(); ++i)
+            if (blks[i].off == off && !blks[i].free) {
+                blks[i].free = true;
+                if (i + 1 < blks.size() && blks[i + 1].free) {
+                    blks[i].size += blks[i + 1].size;
+                    blks.erase(blks.begin() + i + 1);
+                }
+                if (i > 0 && blks[i - 1].free) {
+                    blks[i - 1].size += blks[i].size;
+                    blks.erase(blks.begin() + i);
+                }
+                return;
+            }
+    }
+};
+
+struct Tensor {            // channels-last activation [B][HW_level][C] living in the arena
+    float* p = nullptr;
+    size_t off = 0;
+    int C = 0, level = 0;
+    bool valid = false;
+};
+struct StatsBuf {          // GroupNorm partial sums of a raw conv output
+    double* p = nullptr;
+    size_t off = 0;
+    StatsRef ref{};
+    bool valid = false;
+};
+struct Value {             // a tensor plus the GroupNorm affine still pending on it (if any)
+    Tensor t;
+    StatsBuf st;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    bool pending_gn() const { return st.valid; }
+};
+
+struct ConvW { float* w = nullptr; int taps = 0, cin = 0, cout = 0; };
+struct DoubleConvW { ConvW first, second; float* gamma = nullptr; float* beta = nullptr; };
+struct LinW { float* w = nullptr; float* b = nullptr; int in = 0, out = 0; };
+struct ResampleW { DoubleConvW dc1, dc2; LinW emb, film; float* temb_table = nullptr; int cout = 0; };
+struct AttnW { LinW in_proj, out_proj, ff1, ff2; float* ln_g = nullptr; float* ln_b = nullptr; float* ff_ln_g = nullptr; float* ff_ln_b = nullptr; int C = 0; };
+
+struct ProfEvt { hipEvent_t a, b; double flops; };
+
+struct spdm_handle {
+    spdm_config cfg{};
+    int Hp = 0, Wp = 0, lh = 0, uh = 0, lw = 0, uw = 0;
+    int film_kp = 0;
+    // weights
+    std::vector<void*> owned;             // every hipMalloc to free
+    float* w_inc_first = nullptr;         // [9][64]
+    DoubleConvW inc, bot[3];
+    ResampleW down[3], up[3];
+    AttnW sa[6];
+    float* outc_w = nullptr;
+    float outc_b = 0.f;
+    bool weights_loaded = false, temb_ready = false;
+    std::vector<float> time_table;        // host (T, time_dim)
+    float* d_time_silu = nullptr;         // device SiLU(pos_encoding) (T, time_dim)
+    // schedule
+    int sched_kind = -1, n_steps = 0;
+    std::vector<int> timesteps;
+    int* d_timesteps = nullptr;
+    float* d_coef = nullptr;
+    // persistent per-call state (sized for max_batch)
+    int* d_t = nullptr;                   // [max_batch] timestep(s) of the current evaluation
+    int* d_step = nullptr;                // loop iteration
+    float* d_condm = nullptr;             // Mish(cond), K padded
+    float* d_film[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* d_x = nullptr;                 // current iterate (B,H0,D)
+    bool have_film = false;
+    // sampling session
+    int sB = 0, s_inp_h = 0, s_inp_per_sample = 0;
+    const float* s_inpaint = nullptr;
+    const float* s_noise = nullptr;
+    float* s_history = nullptr;
+    unsigned long long s_seed = 0, s_offset = 0;
+    bool session = false;
+    // arena
+    Arena arena;
+    size_t persistent_bytes = 0;
+    // debug
+    std::map<std::string, Tensor> taps;
+    int tapB = 0;
+    // profiling of the dominant kernel class
+    bool prof = false;
+    std::vector<ProfEvt> prof_evts;
+    long long prof_launches = 0;
+    double prof_ms = 0.0, prof_flops = 0.0;
+};
+
+static int dev_alloc(spdm_handle* h, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    h->owned.push_back(*p);
+    h->persistent_bytes += bytes;
+    return SPDM_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// schedule tables (host, fp32, operation order of diffusers 0.17.1 -- see oracle/scheduler_ref.py)
+#pragma clang fp contract(off)
+static int build_schedule(int kind, int T, int n, float beta_start, float beta_end, int* ts, float* coef) {
+    if (T < 1 || n < 1 || n > T) return fail(SPDM_ERR_INVALID, "schedule: need 1 <= n (%d) <= T (%d)", n, T);
+    if (kind != SPDM_DDPM && kind != SPDM_DDIM) return fail(SPDM_ERR_INVALID, "schedule: unknown kind %d", kind);
+    std::vector<float> acp(T);
+    {   // torch.linspace(fp32): symmetric evaluation from both ends; alphas = 1 - betas; cumprod
+        const float step = (T > 1) ? (beta_end - beta_start) / (float)(T - 1) : 0.f;
+        float run = 1.0f;
+        for (int i = 0; i < T; ++i) {
+            const float beta = (i < T / 2) ? beta_start + step * (float)i : beta_end - step * (float)(T - 1 - i);
+            const float alpha = 1.0f - beta;
+            run = (i == 0) ? alpha : run * alpha;
+            acp[i] = run;
+        }
+    }
+    const int ratio = T / n;
+    for (int i = 0; i < n; ++i) {
+        const int t = (n - 1 - i) * ratio;
+        const int prev_t = t - ratio;
+        ts[i] = t;
+        const float a_t = acp[t];
+        const float a_prev = (prev_t >= 0) ? acp[prev_t] : 1.0f;
+        const float b_t = 1.0f - a_t;
+        float* c = coef + (size_t)i * 6;
+        c[0] = sqrtf(b_t);
+        c[1] = sqrtf(a_t);
+        c[2] = c[3] = c[4] = c[5] = 0.f;
+        if (kind == SPDM_DDPM) {
+            const float b_prev = 1.0f - a_prev;
+            const float cur_a = a_t / a_prev;
+            const float cur_b = 1.0f - cur_a;
+            c[2] = (sqrtf(a_prev) * cur_b) / b_t;
+            c[3] = sqrtf(cur_a) * b_prev / b_t;
+            if (t > 0) {
+                float var = (1.0f - a_prev) / (1.0f - a_t) * cur_b;
+                if (var < 1e-20f) var = 1e-20f;
+                c[5] = sqrtf(var);
+            }
+        } else {
+            c[2] = sqrtf(a_prev);
+            c[4] = sqrtf(1.0f - a_prev - 0.0f);
+        }
+    }
+    return SPDM_OK;
+}
+
+// pos_encoding(t) for t = 0..T-1 (models/Unet_FiLmLayer.py:266-274), default host computation
+static void default_time_table(std::vector<float>& tab, int T, int dim) {
+    tab.resize((size_t)T * dim);
+    const int half = dim / 2;
+    for (int i = 0; i < half; ++i) {
+        const float expo = (float)(2 * i) / (float)dim;
+        const float inv_freq = 1.0f / powf(10000.0f, expo);
+        for (int t = 0; t < T; ++t) {
+            const float arg = (float)t * inv_freq;
+            tab[(size_t)t * dim + i] = sinf(arg);
+            tab[(size_t)t * dim + half + i] = cosf(arg);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+extern "C" int spdm_abi_version(void) { return SPDM_ABI_VERSION; }
+extern "C" const char* spdm_last_error(void) { return g_err; }
+
+extern "C" int spdm_schedule_tables(int32_t kind, int32_t T, int32_t n, float beta_start, float beta_end,
+                                    int32_t* ts, float* coef) {
+    if (!ts || !coef) return fail(SPDM_ERR_INVALID, "null output");
+    return build_schedule(kind, T, n, beta_start, beta_end, ts, coef);
+}
+
+static int plan_forward(spdm_handle* h, int B, bool use_cond, hipStream_t s, Tensor* feat_out);
+
+// channel / tap geometry of every layer (UNet_Film.__init__, models/Unet_FiLmLayer.py:246-264); known
+// before any weight is loaded, so that create() can size the workspace with a dry run of the plan
+static void init_arch(spdm_handle* h) {
+    // level-3 maps are (Hp/8) x 1: a 3x3 kernel only ever multiplies its centre column there
+    const int t3 = (h->Wp >> 3) == 1 ? 3 : 9;
+    auto dc = [](DoubleConvW& d, int cin, int cout, int taps) {
+        d.first.cin = cin; d.first.cout = cout; d.first.taps = taps;
+        d.second.cin = cout; d.second.cout = cout; d.second.taps = taps;
+    };
+    auto rs = [&](ResampleW& r, int cin, int cout, int taps) {
+        dc(r.dc1, cin, cin, taps);
+        dc(r.dc2, cin, cout, taps);
+        r.cout = cout;
+    };
+    dc(h->inc, 1, 64, 9);
+    rs(h->down[0], 64, 128, 9);
+    rs(h->down[1], 128, 256, 9);
+    rs(h->down[2], 256, 256, t3);
+    dc(h->bot[0], 256, 512, t3);
+    dc(h->bot[1], 512, 512, t3);
+    dc(h->bot[2], 512, 256, t3);
+    rs(h->up[0], 512, 128, 9);
+    rs(h->up[1], 256, 64, 9);
+    rs(h->up[2], 128, 64, 9);
+    static const int sc[6] = {128, 256, 256, 128, 64, 64};
+    for (int i = 0; i < 6; ++i) h->sa[i].C = sc[i];
+}
+
+extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
+    if (!cfg || !out) return fail(SPDM_ERR_INVALID, "null argument");
+    if (cfg->horizon < 1 || cfg->state_dim < 1 || cfg->state_dim > 8)
+        return fail(SPDM_ERR_INVALID, "horizon must be >= 1 and 1 <= state_dim <= 8 (got %d, %d)", cfg->horizon, cfg->state_dim);
+    if (cfg->time_dim < 32 || cfg->time_dim % 32 != 0) return fail(SPDM_ERR_INVALID, "time_dim must be a multiple of 32");
+    if (cfg->cond_dim < 0 || cfg->max_batch < 1 || cfg->num_train_timesteps < 1)
+        return fail(SPDM_ERR_INVALID, "cond_dim >= 0, max_batch >= 1, num_train_timesteps >= 1 required");
+    HIP_TRY(hipSetDevice(cfg->device));
+    spdm_handle* h = new spdm_handle();
+    h->cfg = *cfg;
+    // pad_to(x, 8): models/Unet_FiLmLayer.py:15-28
+    const int H0 = cfg->horizon, D = cfg->state_dim;
+    h->Hp = (H0 % 8) ? H0 + 8 - H0 % 8 : H0;
+    h->Wp = (D % 8) ? D + 8 - D % 8 : D;
+    h->lh = (h->Hp - H0) / 2;  h->uh = (h->Hp - H0) - h->lh;
+    h->lw = (h->Wp - D) / 2;   h->uw = (h->Wp - D) - h->lw;
+    h->film_kp = (int)align_up((size_t)std::max(cfg->cond_dim, 1), 32);
+    const int mb = cfg->max_batch;
+    init_arch(h);
+    int rc = SPDM_OK;
+    do {
+        if ((rc = dev_alloc(h, (void**)&h->d_t, sizeof(int) * mb))) break;
+        if ((rc = dev_alloc(h, (void**)&h->d_step, sizeof(int) * 4))) break;
+        if ((rc = dev_alloc(h, (void**)&h->d_condm, sizeof(float) * (size_t)mb * h->film_kp))) break;
+        static const int film_c[6] = {128, 256, 256, 128, 64, 64};
+        for (int i = 0; i < 6 && !rc; ++i) rc = dev_alloc(h, (void**)&h->d_film[i], sizeof(float) * (size_t)mb * 2 * film_c[i]);
+        if (rc) break;
+        if ((rc = dev_alloc(h, (void**)&h->d_x, sizeof(float) * (size_t)mb * H0 * D))) break;
+        // size the arena with a dry run of the plan at max_batch
+        h->arena.dry = true;
+        h->arena.keep = (cfg->flags & SPDM_FLAG_DEBUG_KEEP) != 0;
+        h->arena.reset();
+        Tensor feat;
+        if ((rc = plan_forward(h, mb, true, nullptr, &feat))) break;
+        h->arena.dry = false;
+        h->arena.cap = align_up(h->arena.peak, 4096);
+        hipError_t e = hipMalloc((void**)&h->arena.base, h->arena.cap);
+        if (e != hipSuccess) { rc = fail(SPDM_ERR_NOMEM, "workspace of %zu bytes: %s", h->arena.cap, hipGetErrorString(e)); break; }
+        h->owned.push_back(h->arena.base);
+    } while (0);
+    if (rc) { spdm_destroy(h); return rc; }
+    default_time_table(h->time_table, cfg->num_train_timesteps, cfg->time_dim);
+    *out = h;
+    return SPDM_OK;
+}
+
+extern "C" void spdm_destroy(spdm_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : h->owned) (void)hipFree(p);
+    for (auto& e : h->prof_evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete h;
+}
+
+extern "C" size_t spdm_device_bytes(const spdm_handle* h) { return h ? h->persistent_bytes + h->arena.cap : 0; }
+
+// -------------------------------------------------------------------------------------------------
+// weights
+struct Loader {
+    spdm_handle* h;
+    const float* blob;
+    size_t n;
+    std::map<std::string, const spdm_tensor_index*> idx;
+    int err = SPDM_OK;
+    const float* find(const std::string& name, std::initializer_list<int> shape) {
+        auto it = idx.find(name);
+        if (it == idx.end()) { err = fail(SPDM_ERR_MISSING, "tensor '%s' not in the index", name.c_str()); return nullptr; }
+        const spdm_tensor_index* e = it->second;
+        size_t numel = 1;
+        int d = 0;
+        for (int sdim : shape) {
+            if (d >= e->ndim || e->shape[d] != sdim) { err = fail(SPDM_ERR_INVALID, "tensor '%s': unexpected shape", name.c_str()); return nullptr; }
+            numel *= (size_t)sdim;
+            ++d;
+        }
+        if (d != e->ndim || numel != e->numel || e->offset + e->numel > n) { err = fail(SPDM_ERR_INVALID, "tensor '%s': bad extent", name.c_str()); return nullptr; }
+        return blob + e->offset;
+    }
+    float* upload(const std::vector<float>& v) {
+        void* p = nullptr;
+        if (dev_alloc(h, &p, v.size() * sizeof(float)) != SPDM_OK) { err = SPDM_ERR_HIP; return nullptr; }
+        if (hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            err = fail(SPDM_ERR_HIP, "weight upload failed");
+            return nullptr;
+        }
+        return (float*)p;
+    }
+    // (Cout,Cin,3,3) -> [taps][Cout][Cin]; taps == 3 keeps only the centre column (W == 1 levels, where
+    // the left/right taps only ever see zero padding)
+    ConvW conv(const std::string& name, int cout, int cin, int taps) {
+        ConvW c;
+        const float* src = find(name, {cout, cin, 3, 3});
+        if (!src) return c;
+        std::vector<float> v((size_t)taps * cout * cin);
+        for (int t = 0; t < taps; ++t) {
+            const int kh = (taps == 9) ? t / 3 : t, kw = (taps == 9) ? t % 3 : 1;
+            for (int o = 0; o < cout; ++o)
+                for (int i = 0; i < cin; ++i)
+                    v[((size_t)t * cout + o) * cin + i] = src[(((size_t)o * cin + i) * 3 + kh) * 3 + kw];
+        }
+        c.w = upload(v);
+        c.taps = taps; c.cin = cin; c.cout = cout;
+        return c;
+    }
+    float* vec(const std::string& name, int nelem) {
+        const float* src = find(name, {nelem});
+        if (!src) return nullptr;
+        return upload(std::vector<float>(src, src + nelem));
+    }
+    LinW linear(const std::string& wname, const std::string& bname, int out, int in, int in_pad) {
+        LinW l;
+        const float* w = find(wname, {out, in});
+        if (!w) return l;
+        std::vector<float> v((size_t)out * in_pad, 0.f);
+        for (int o = 0; o < out; ++o) memcpy(&v[(size_t)o * in_pad], w + (size_t)o * in, sizeof(float) * in);
+        l.w = upload(v);
+        l.b = vec(bname, out);
+        l.in = in_pad; l.out = out;
+        return l;
+    }
+    DoubleConvW dconv(const std::string& p, int cin, int cout, int taps) {
+        DoubleConvW d;
+        d.first = conv(p + ".first.weight", cout, cin, taps);
+        d.second = conv(p + ".second.weight", cout, cout, taps);
+        d.gamma = vec(p + ".norm.weight", cout);
+        d.beta = vec(p + ".norm.bias", cout);
+        return d;
+    }
+    ResampleW resample(const std::string& p, int cin, int cout, int taps) {
+        ResampleW r;
+        r.dc1 = dconv(p + ".doubleConv1", cin, cin, taps);
+        r.dc2 = dconv(p + ".doubleConv2", cin, cout, taps);
+        r.emb = linear(p + ".emb_layer.1.weight", p + ".emb_layer.1.bias", cout, h->cfg.time_dim, h->cfg.time_dim);
+        if (h->cfg.cond_dim > 0)
+            r.film = linear(p + ".cond_encoder.2.weight", p + ".cond_encoder.2.bias", 2 * cout, h->cfg.cond_dim, h->film_kp);
+        r.cout = cout;
+        return r;
+    }
+    AttnW attn(const std::string& p, int C) {
+        AttnW a;
+        a.C = C;
+        a.in_proj = linear(p + ".attention.in_proj_weight", p + ".attention.in_proj_bias", 3 * C, C, C);
+        a.out_proj = linear(p + ".attention.out_proj.weight", p + ".attention.out_proj.bias", C, C, C);
+        a.ln_g = vec(p + ".ln.weight", C);
+        a.ln_b = vec(p + ".ln.bias", C);
+        a.ff_ln_g = vec(p + ".ff_self.0.weight", C);
+        a.ff_ln_b = vec(p + ".ff_self.0.bias", C);
+        a.ff1 = linear(p + ".ff_self.1.weight", p + ".ff_self.1.bias", C, C, C);
+        a.ff2 = linear(p + ".ff_self.3.weight", p + ".ff_self.3.bias", C, C, C);
+        return a;
+    }
+};
+
+extern "C" int spdm_load_weights(spdm_handle* h, const float* blob, size_t n, const spdm_tensor_index* index,
+                                 int32_t n_index) {
+    if (!h || !blob || !index || n_index <= 0) return fail(SPDM_ERR_INVALID, "null argument");
+    if (h->weights_loaded) return fail(SPDM_ERR_STATE, "weights already loaded on this handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    Loader L{h, blob, n};
+    for (int i = 0; i < n_index; ++i) {
+        char name[SPDM_NAME_MAX + 1];
+        memcpy(name, index[i].name, SPDM_NAME_MAX);
+        name[SPDM_NAME_MAX] = 0;
+        L.idx[name] = &index[i];
+    }
+    // level-3 maps are (Hp/8) x 1: a 3x3 kernel only ever multiplies its centre column there
+    const int t3 = (h->Wp >> 3) == 1 ? 3 : 9;
+    {   // inc.first (64,1,3,3) -> [9][64]
+        const float* src = L.find("inc.first.weight", {64, 1, 3, 3});
+        if (src) {
+            std::vector<float> v(9 * 64);
+            for (int t = 0; t < 9; ++t)
+                for (int o = 0; o < 64; ++o) v[t * 64 + o] = src[o * 9 + t];
+            h->w_inc_first = L.upload(v);
+        }
+    }
+    h->inc.second = L.conv("inc.second.weight", 64, 64, 9);
+    h->inc.gamma = L.vec("inc.norm.weight", 64);
+    h->inc.beta = L.vec("inc.norm.bias", 64);
+    h->down[0] = L.resample("down1", 64, 128, 9);
+    h->down[1] = L.resample("down2", 128, 256, 9);
+    h->down[2] = L.resample("down3", 256, 256, t3);
+    h->bot[0] = L.dconv("bot1", 256, 512, t3);
+    h->bot[1] = L.dconv("bot2", 512, 512, t3);
+    h->bot[2] = L.dconv("bot3", 512, 256, t3);
+    h->up[0] = L.resample("up1", 512, 128, 9);
+    h->up[1] = L.resample("up2", 256, 64, 9);
+    h->up[2] = L.resample("up3", 128, 64, 9);
+    if (h->cfg.attention) {
+        static const int sc[6] = {128, 256, 256, 128, 64, 64};
+        for (int i = 0; i < 6; ++i) h->sa[i] = L.attn("sa" + std::to_string(i + 1), sc[i]);
+    }
+    h->outc_w = nullptr;
+    {
+        const float* w = L.find("outc.weight", {1, 64, 1, 1});
+        const float* b = L.find("outc.bias", {1});
+        if (w && b) {
+            h->outc_w = L.upload(std::vector<float>(w, w + 64));
+            h->outc_b = b[0];
+        }
+    }
+    if (L.err != SPDM_OK) return L.err;
+    // time-embedding tables (one per resample block), filled lazily on the first evaluation
+    ResampleW* blocks[6] = {&h->down[0], &h->down[1], &h->down[2], &h->up[0], &h->up[1], &h->up[2]};
+    for (ResampleW* r : blocks)
+        SPDM_TRY(dev_alloc(h, (void**)&r->temb_table, sizeof(float) * (size_t)h->cfg.num_train_timesteps * r->cout));
+    SPDM_TRY(dev_alloc(h, (void**)&h->d_time_silu, sizeof(float) * (size_t)h->cfg.num_train_timesteps * h->cfg.time_dim));
+    h->weights_loaded = true;
+    h->temb_ready = false;
+    return SPDM_OK;
+}
+
+extern "C" int spdm_set_time_table(spdm_handle* h, const float* tab, int32_t T) {
+    if (!h || !tab) return fail(SPDM_ERR_INVALID, "null argument");
+    if (T != h->cfg.num_train_timesteps) return fail(SPDM_ERR_INVALID, "time table has %d rows, handle was created for %d", T, h->cfg.num_train_timesteps);
+    h->time_table.assign(tab, tab + (size_t)T * h->cfg.time_dim);
+    h->temb_ready = false;
+    return SPDM_OK;
+}
+
+static int install_schedule(spdm_handle* h, int kind, int n, const int* ts, const float* coef) {
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (int i = 0; i < n; ++i)
+        if (ts[i] < 0 || ts[i] >= h->cfg.num_train_timesteps)
+            return fail(SPDM_ERR_INVALID, "timestep %d outside the handle's time table [0,%d)", ts[i], h->cfg.num_train_timesteps);
+    if (n > h->n_steps || !h->d_coef) {
+        SPDM_TRY(dev_alloc(h, (void**)&h->d_timesteps, sizeof(int) * n));
+        SPDM_TRY(dev_alloc(h, (void**)&h->d_coef, sizeof(float) * 6 * n));
+    }
+    HIP_TRY(hipMemcpy(h->d_timesteps, ts, sizeof(int) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_coef, coef, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+    h->timesteps.assign(ts, ts + n);
+    h->n_steps = n;
+    h->sched_kind = kind;
+    h->session = false;
+    return SPDM_OK;
+}
+
+extern "C" int spdm_set_schedule(spdm_handle* h, int32_t kind, int32_t T, int32_t n, float b0, float b1) {
+    if (!h) return fail(SPDM_ERR_INVALID, "null handle");
+    if (T > h->cfg.num_train_timesteps) return fail(SPDM_ERR_INVALID, "T = %d exceeds the handle's time table (%d)", T, h->cfg.num_train_timesteps);
+    std::vector<int> ts(std::max(n, 1));
+    std::vector<float> coef((size_t)std::max(n, 1) * 6);
+    SPDM_TRY(build_schedule(kind, T, n, b0, b1, ts.data(), coef.data()));
+    return install_schedule(h, kind, n, ts.data(), coef.data());
+}
+
+extern "C" int spdm_set_schedule_tables(spdm_handle* h, int32_t kind, int32_t n, const int32_t* ts, const float* coef) {
+    if (!h || !ts || !coef || n < 1) return fail(SPDM_ERR_INVALID, "bad argument");
+    if (kind != SPDM_DDPM && kind != SPDM_DDIM) return fail(SPDM_ERR_INVALID, "unknown scheduler kind %d", kind);
+    return install_schedule(h, kind, n, ts, coef);
+}
+
+// -------------------------------------------------------------------------------------------------
+// plan helpers
+struct Ctx {
+    spdm_handle* h;
+    int B;
+    hipStream_t s;
+    bool dry;
+    int err = SPDM_OK;
+    int HWl(int l) const { return (h->Hp >> l) * (h->Wp >> l); }
+    int Hl(int l) const { return h->Hp >> l; }
+    int Wl(int l) const { return h->Wp >> l; }
+
+    Tensor talloc(int C, int level) {
+        Tensor t;
+        t.C = C; t.level = level;
+        size_t off = 0;
+        if (!h->arena.alloc(sizeof(float) * (size_t)B * HWl(level) * C, &off)) {
+            if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
+            return t;
+        }
+        t.off = off; t.p = (float*)(h->arena.base + off); t.valid = true;
+        return t;
+    }
+    Tensor ralloc(int rows, int C) {       // [rows][C] scratch (attention path)
+        Tensor t;
+        t.C = C; t.level = -1;
+        size_t off = 0;
+        if (!h->arena.alloc(sizeof(float) * (size_t)rows * C, &off)) {
+            if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
+            return t;
+        }
+        t.off = off; t.p = (float*)(h->arena.base + off); t.valid = true;
+        return t;
+    }
+    StatsBuf salloc(int HW, int C, int m_tile, int n_tiles) {
+        StatsBuf sb;
+        const int slots = stats_slots(HW, m_tile, n_tiles);
+        size_t off = 0;
+        if (!h->arena.alloc(sizeof(double) * 2 * (size_t)B * slots, &off)) {
+            if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
+            return sb;
+        }
+        sb.off = off; sb.p = (double*)(h->arena.base + off); sb.valid = true;
+        sb.ref.p = sb.p; sb.ref.slots = slots; sb.ref.m_tile = m_tile; sb.ref.n_tiles = n_tiles; sb.ref.HW = HW;
+        sb.ref.inv_count = 1.0 / ((double)C * (double)HW);
+        return sb;
+    }
+    void free(Tensor& t) { if (t.valid) { h->arena.release(t.off); t.valid = false; } }
+    void free(StatsBuf& s2) { if (s2.valid) { h->arena.release(s2.off); s2.valid = false; } }
+    void free(Value& v) { free(v.t); free(v.st); }
+    void check(hipError_t e, const char* what) {
+        if (e != hipSuccess && !err) err = fail(SPDM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+    AffineSrc asrc(const Value& v) const {
+        AffineSrc a{};
+        a.x = v.t.p; a.C = v.t.C;
+        if (v.pending_gn()) { a.st = v.st.ref; a.gamma = v.gamma; a.beta = v.beta; }
+        else { a.st = StatsRef{}; a.st.p = nullptr; a.gamma = nullptr; a.beta = nullptr; }
+        return a;
+    }
+    void tap(const char* name, const Tensor& t) {
+        if (h->arena.keep && !dry) { h->taps[name] = t; h->tapB = B; }
+    }
+
+    // one 3x3 conv: reads `in` (finishing its pending GroupNorm, + GELU if asked, in the load
+    // prologue), writes the raw output and its GroupNorm partial sums
+    Value conv(const Value& in, const ConvW& w, int level, bool gelu, const float* gamma, const float* beta) {
+        Value out;
+        const int HW = HWl(level), M = B * HW;
+        const GemmGeom g = gemm_geometry(M, w.cout, HW);
+        out.t = talloc(w.cout, level);
+        out.st = salloc(HW, w.cout, g.m_tile, g.n_tiles);
+        out.gamma = gamma; out.beta = beta;
+        if (err || dry) return out;
+        GemmArgs a{};
+        a.src = in.t.p; a.src_ld = in.t.C; a.wgt = w.w; a.dst = out.t.p; a.dst_ld = w.cout;
+        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
+        a.H = Hl(level); a.W = Wl(level); a.HW = HW;
+        a.pro = in.pending_gn() ? (gelu ? PRO_GN_GELU : PRO_GN) : PRO_NONE;
+        if (in.pending_gn()) { a.pro_stats = in.st.ref; a.pro_gamma = in.gamma; a.pro_beta = in.beta; }
+        a.epi = EPI_STATS; a.epi_stats = out.st.p;
+        if (in.t.C != w.cin) { if (!err) err = fail(SPDM_ERR_INVALID, "plan: conv input has %d channels, weight expects %d", in.t.C, w.cin); return out; }
+        ProfEvt* pe = nullptr;
+        if (h->prof) {
+            ProfEvt e{};
+            if (hipEventCreate(&e.a) == hipSuccess && hipEventCreate(&e.b) == hipSuccess) {
+                e.flops = gemm_flops(a);
+                h->prof_evts.push_back(e);
+                pe = &h->prof_evts.back();
+                (void)hipEventRecord(pe->a, s);
+            }
+        }
+        check(launch_gemm(a, s), "conv3x3 implicit GEMM");
+        if (pe) (void)hipEventRecord(pe->b, s);
+        return out;
+    }
+    // DoubleConvolution.forward, models/Unet_FiLmLayer.py:108-115.  Consumes `in`.
+    Value double_conv(Value& in, const DoubleConvW& w, int level, bool keep_in = false) {
+        Value mid = conv(in, w.first, level, /*gelu=*/false, w.gamma, w.beta);
+        if (!keep_in) free(in);
+        Value out = conv(mid, w.second, level, /*gelu=*/true, w.gamma, w.beta);
+        free(mid);
+        return out;
+    }
+    // y[rows][N] = x[rows][K] @ W^T + b  (+GELU | +resid)
+    void linear(const float* x, int ld, int rows, const LinW& w, float* y, int epi, const float* resid) {
+        if (err || dry) return;
+        GemmArgs a{};
+        a.src = x; a.src_ld = ld; a.wgt = w.w; a.dst = y; a.dst_ld = w.out;
+        a.M = rows; a.K = w.in; a.N = w.out; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
+        a.pro = PRO_NONE; a.epi = epi; a.bias = w.b; a.resid = resid; a.resid_ld = w.out;
+        check(launch_gemm(a, s), "linear GEMM");
+    }
+    // SelfAttention.forward, models/Unet_FiLmLayer.py:71-82.  Consumes x, returns the block output.
+    Tensor attention(Tensor& x, const AttnW& w, int level) {
+        const int L = HWl(level), rows = B * L, C = w.C;
+        Tensor ln = ralloc(rows, C);
+        if (!err && !dry) check(launch_layernorm(x.p, w.ln_g, w.ln_b, ln.p, rows, C, s), "layernorm");
+        Tensor qkv = ralloc(rows, 3 * C);
+        linear(ln.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr);
+        free(ln);
+        Tensor att = ralloc(rows, C);
+        if (!err && !dry) check(launch_attention(qkv.p, att.p, B, L, C, 4, s), "attention core");
+        free(qkv);
+        Tensor av = talloc(C, level);
+        linear(att.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p);
+        free(att);
+        free(x);
+        Tensor ln2 = ralloc(rows, C);
+        if (!err && !dry) check(launch_layernorm(av.p, w.ff_ln_g, w.ff_ln_b, ln2.p, rows, C, s), "layernorm");
+        Tensor f1 = ralloc(rows, C);
+        linear(ln2.p, C, rows, w.ff1, f1.p, EPI_BIAS_GELU, nullptr);
+        free(ln2);
+        Tensor out = talloc(C, level);
+        linear(f1.p, C, rows, w.ff2, out.p, EPI_BIAS_RESID, av.p);
+        free(f1);
+        free(av);
+        return out;
+    }
+    // tail of DownSample/UpSample.forward: + time embedding, FiLM.  Consumes v.
+    Tensor film_tail(Value& v, const ResampleW& w, int blk, int level, bool use_cond) {
+        Tensor y = talloc(w.cout, level);
+        if (!err && !dry)
+            check(launch_film_apply(asrc(v), w.temb_table, h->d_t, (h_tcount), (use_cond && h->cfg.cond_dim > 0) ? h->d_film[blk] : nullptr,
+                                    y.p, B, HWl(level), s), "film_apply");
+        free(v);
+        return y;
+    }
+    int h_tcount = 1;
+};
+
+// one U-Net evaluation on h->d_x... : x (B,H0,D) -> feat (B, Hp*Wp, 64)
+static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
+    spdm_handle* h = c.h;
+    const int B = c.B;
+    // ---- inc = DoubleConvolution(1, 64) on the zero-padded trajectory (:286-288) ----
+    Value v0;
+    v0.t = c.talloc(64, 0);
+    v0.st = c.salloc(c.HWl(0), 64, c.HWl(0), 1);
+    v0.gamma = h->inc.gamma; v0.beta = h->inc.beta;
+    if (!c.err && !c.dry)
+        c.check(launch_conv_in(x, h->w_inc_first, v0.t.p, v0.st.p, B, h->cfg.horizon, h->cfg.state_dim, h->Hp, h->Wp,
+                               h->lh, h->lw, c.s), "conv_in");
+    Value x1 = c.conv(v0, h->inc.second, 0, /*gelu=*/true, h->inc.gamma, h->inc.beta);   // x1 = GN(raw), pending
+    c.free(v0);
+    if (h->arena.keep && !c.dry && !c.err) {
+        Tensor m = c.talloc(64, 0);
+        c.check(launch_gn_apply(c.asrc(x1), m.p, B, c.HWl(0), c.s), "gn_apply");
+        c.tap("x1", m);
+    }
+
+    // ---- encoder: down1..3 (+ sa1..3) ----
+    Value skips[3];            // x1 (pending GN), x2, x3 (materialised)
+    skips[0] = x1;
+    Value cur = x1;
+    static const char* dn[3] = {"d1", "d2", "d3"};
+    static const char* xn[3] = {"x2", "x3", "x4"};
+    for (int i = 0; i < 3; ++i) {
+        const int lin = i, lout = i + 1;
+        Value p;
+        p.t = c.talloc(cur.t.C, lout);
+        if (!c.err && !c.dry)
+            c.check(launch_pool(c.asrc(cur), p.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "maxpool");
+        // `cur` stays alive: it is a skip connection
+        Value a = c.double_conv(p, h->down[i].dc1, lout);
+        Value b2 = c.double_conv(a, h->down[i].dc2, lout);
+        Tensor y = c.film_tail(b2, h->down[i], i, lout, use_cond);
+        c.tap(dn[i], y);
+        if (h->cfg.attention) y = c.attention(y, h->sa[i], lout);
+        c.tap(xn[i], y);
+        Value nv;
+        nv.t = y;
+        cur = nv;
+        if (i < 2) skips[i + 1] = nv;
+    }
+    // ---- bottleneck (:297-299) ----
+    Value b1 = c.double_conv(cur, h->bot[0], 3);
+    Value b2 = c.double_conv(b1, h->bot[1], 3);
+    Value x5 = c.double_conv(b2, h->bot[2], 3);         // pending GN
+    if (h->arena.keep && !c.dry && !c.err) {
+        Tensor m = c.talloc(256, 3);
+        c.check(launch_gn_apply(c.asrc(x5), m.p, B, c.HWl(3), c.s), "gn_apply");
+        c.tap("x5", m);
+    }
+    // ---- decoder: up1..3 (+ sa4..6) ----
+    static const char* un[3] = {"u1", "u2", "u3"};
+    static const char* an[3] = {"a4", "a5", "a6"};
+    cur = x5;
+    for (int i = 0; i < 3; ++i) {
+        const int lin = 3 - i, lout = 2 - i;
+        Value& skip = skips[2 - i];
+        Value cat;
+        cat.t = c.talloc(cur.t.C + skip.t.C, lout);
+        if (!c.err && !c.dry)
+            c.check(launch_upcat(c.asrc(cur), c.asrc(skip), cat.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "upsample+concat");
+        c.free(cur);
+        c.free(skip);
+        Value a = c.double_conv(cat, h->up[i].dc1, lout);
+        Value b3 = c.double_conv(a, h->up[i].dc2, lout);
+        Tensor y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond);
+        c.tap(un[i], y);
+        if (h->cfg.attention) y = c.attention(y, h->sa[3 + i], lout);
+        c.tap(an[i], y);
+        Value nv;
+        nv.t = y;
+        cur = nv;
+    }
+    *feat_out = cur.t;
+    return c.err;
+}
+
+static int plan_forward(spdm_handle* h, int B, bool use_cond, hipStream_t s, Tensor* feat_out) {
+    Ctx c{h, B, s, h->arena.dry};
+    h->arena.reset();
+    return plan_unet(c, h->d_x, use_cond, feat_out);
+}
+
+// time-embedding tables: Linear(SiLU(pos_encoding(t))) for every t (models/Unet_FiLmLayer.py:136-142)
+static int ensure_temb(spdm_handle* h, hipStream_t s) {
+    if (h->temb_ready) return SPDM_OK;
+    const int T = h->cfg.num_train_timesteps, dim = h->cfg.time_dim;
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, sizeof(float) * (size_t)T * dim));
+    hipError_t e = hipMemcpyAsync(tmp, h->time_table.data(), sizeof(float) * (size_t)T * dim, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_silu(tmp, h->d_time_silu, (size_t)T * dim, s);
+    ResampleW* blocks[6] = {&h->down[0], &h->down[1], &h->down[2], &h->up[0], &h->up[1], &h->up[2]};
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) {
+        GemmArgs a{};
+        a.src = h->d_time_silu; a.src_ld = dim; a.wgt = blocks[i]->emb.w; a.dst = blocks[i]->temb_table; a.dst_ld = blocks[i]->cout;
+        a.M = T; a.K = dim; a.N = blocks[i]->cout; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
+        a.pro = PRO_NONE; a.epi = EPI_BIAS; a.bias = blocks[i]->emb.b;
+        e = launch_gemm(a, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(SPDM_ERR_HIP, "time-embedding tables: %s", hipGetErrorString(e));
+    h->temb_ready = true;
+    return SPDM_OK;
+}
+
+// FiLM projections [scale | bias] = Linear(Mish(flatten(cond))) for the six resample blocks
+// (models/Unet_FiLmLayer.py:149-154,171-175).  Step-invariant: hoisted out of the denoise loop.
+static int compute_film(spdm_handle* h, int B, const float* d_cond, hipStream_t s) {
+    h->have_film = false;
+    if (!d_cond || h->cfg.cond_dim <= 0) return SPDM_OK;
+    hipError_t e = launch_mish_pad(d_cond, h->d_condm, B, h->cfg.cond_dim, h->film_kp, s);
+    ResampleW* blocks[6] = {&h->down[0], &h->down[1], &h->down[2], &h->up[0], &h->up[1], &h->up[2]};
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) {
+        GemmArgs a{};
+        a.src = h->d_condm; a.src_ld = h->film_kp; a.wgt = blocks[i]->film.w; a.dst = h->d_film[i]; a.dst_ld = 2 * blocks[i]->cout;
+        a.M = B; a.K = h->film_kp; a.N = 2 * blocks[i]->cout; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
+        a.pro = PRO_NONE; a.epi = EPI_BIAS; a.bias = blocks[i]->film.b;
+        e = launch_gemm(a, s);
+    }
+    if (e != hipSuccess) return fail(SPDM_ERR_HIP, "FiLM projections: %s", hipGetErrorString(e));
+    h->have_film = true;
+    return SPDM_OK;
+}
+
+static int check_ready(spdm_handle* h, int B) {
+    if (!h) return fail(SPDM_ERR_INVALID, "null handle");
+    if (!h->weights_loaded) return fail(SPDM_ERR_STATE, "spdm_load_weights has not been called");
+    if (B < 1 || B > h->cfg.max_batch) return fail(SPDM_ERR_INVALID, "batch %d outside [1, max_batch = %d]", B, h->cfg.max_batch);
+    return SPDM_OK;
+}
+
+static StepArgs step_args(spdm_handle* h, int B, const Tensor& feat) {
+    StepArgs a{};
+    a.feat = feat.p; a.w = h->outc_w; a.bias = h->outc_b; a.x = h->d_x; a.eps_out = nullptr;
+    a.coef = h->d_coef; a.step_dev = h->d_step; a.kind = h->sched_kind;
+    a.noise = h->s_noise; a.seed = h->s_seed; a.sample_offset = h->s_offset;
+    a.inpaint = h->s_inpaint; a.inp_h = h->s_inp_h; a.inpaint_per_sample = h->s_inp_per_sample;
+    a.history = h->s_history;
+    a.B = B; a.H0 = h->cfg.horizon; a.D = h->cfg.state_dim; a.Hp = h->Hp; a.Wp = h->Wp; a.lh = h->lh; a.lw = h->lw;
+    return a;
+}
+
+extern "C" int spdm_unet_forward(spdm_handle* h, int32_t B, const float* d_x, const int32_t* h_t, int32_t t_count,
+                                 const float* d_cond, float* d_eps, void* stream) {
+    SPDM_TRY(check_ready(h, B));
+    if (!d_x || !h_t || !d_eps) return fail(SPDM_ERR_INVALID, "null argument");
+    if (t_count != 1 && t_count != B) return fail(SPDM_ERR_INVALID, "t_count must be 1 or B");
+    for (int i = 0; i < t_count; ++i)
+        if (h_t[i] < 0 || h_t[i] >= h->cfg.num_train_timesteps) return fail(SPDM_ERR_INVALID, "t = %d outside [0,%d)", h_t[i], h->cfg.num_train_timesteps);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    SPDM_TRY(ensure_temb(h, s));
+    HIP_TRY(hipMemcpyAsync(h->d_t, h_t, sizeof(int) * t_count, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_x, d_x, sizeof(float) * (size_t)B * h->cfg.horizon * h->cfg.state_dim, hipMemcpyDeviceToDevice, s));
+    SPDM_TRY(compute_film(h, B, d_cond, s));
+    h->taps.clear();
+    Ctx c{h, B, s, false};
+    c.h_tcount = t_count;
+    h->arena.reset();
+    Tensor feat;
+    SPDM_TRY(plan_unet(c, h->d_x, d_cond != nullptr, &feat));
+    StepArgs a = step_args(h, B, feat);
+    a.eps_out = d_eps;
+    HIP_TRY(launch_out_step(a, s));
+    h->session = false;
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return SPDM_OK;
+}
+
+extern "C" int spdm_sample_begin(spdm_handle* h, int32_t B, const float* d_cond, const float* d_inpaint, int32_t inp_h,
+                                 int32_t inpaint_per_sample, const float* d_xT, const float* d_noise, uint64_t seed,
+                                 uint64_t sample_offset, float* d_history, void* stream) {
+    SPDM_TRY(check_ready(h, B));
+    if (h->sched_kind < 0) return fail(SPDM_ERR_STATE, "no schedule set (spdm_set_schedule)");
+    if (!d_xT) return fail(SPDM_ERR_INVALID, "d_xT is null");
+    if (inp_h < 0 || inp_h > h->cfg.horizon) return fail(SPDM_ERR_INVALID, "inpaint horizon %d outside [0,%d]", inp_h, h->cfg.horizon);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    SPDM_TRY(ensure_temb(h, s));
+    const size_t nx = (size_t)B * h->cfg.horizon * h->cfg.state_dim;
+    HIP_TRY(hipMemcpyAsync(h->d_x, d_xT, sizeof(float) * nx, hipMemcpyDeviceToDevice, s));
+    if (d_history) HIP_TRY(hipMemcpyAsync(d_history, d_xT, sizeof(float) * nx, hipMemcpyDeviceToDevice, s));
+    SPDM_TRY(compute_film(h, B, d_cond, s));
+    h->sB = B;
+    h->s_inpaint = (inp_h > 0) ? d_inpaint : nullptr;
+    h->s_inp_h = (d_inpaint != nullptr) ? inp_h : 0;
+    h->s_inp_per_sample = inpaint_per_sample;
+    h->s_noise = d_noise;
+    h->s_history = d_history;
+    h->s_seed = seed;
+    h->s_offset = sample_offset;
+    h->session = true;
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return SPDM_OK;
+}
+
+extern "C" int spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_end, void* stream) {
+    if (!h || !h->session) return fail(SPDM_ERR_STATE, "spdm_sample_begin has not been called");
+    if (step_begin < 0 || step_end > h->n_steps || step_begin > step_end)
+        return fail(SPDM_ERR_INVALID, "step range [%d,%d) outside [0,%d]", step_begin, step_end, h->n_steps);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const int B = h->sB;
+    for (int i = step_begin; i < step_end; ++i) {
+        HIP_TRY(launch_set_step(h->d_step, h->d_t, h->d_timesteps, h->n_steps, i, s));
+        Ctx c{h, B, s, false};
+        c.h_tcount = 1;
+        h->arena.reset();
+        Tensor feat;
+        SPDM_TRY(plan_unet(c, h->d_x, h->have_film, &feat));
+        StepArgs a = step_args(h, B, feat);
+        HIP_TRY(launch_out_step(a, s));
+    }
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return SPDM_OK;
+}
+
+extern "C" int spdm_sample_result(spdm_handle* h, float* d_out, void* stream) {
+    if (!h || !h->session) return fail(SPDM_ERR_STATE, "spdm_sample_begin has not been called");
+    if (!d_out) return fail(SPDM_ERR_INVALID, "d_out is null");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(d_out, h->d_x, sizeof(float) * (size_t)h->sB * h->cfg.horizon * h->cfg.state_dim,
+                           hipMemcpyDeviceToDevice, s));
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return SPDM_OK;
+}
+
+extern "C" int spdm_sample(spdm_handle* h, int32_t B, const float* d_cond, const float* d_inpaint, int32_t inp_h,
+                           int32_t inpaint_per_sample, const float* d_xT, const float* d_noise, uint64_t seed,
+                           uint64_t sample_offset, float* d_out, float* d_history, void* stream) {
+    // the three pieces run asynchronously on the caller's stream (or on a private one for NULL)
+    hipStream_t s = (hipStream_t)stream;
+    hipStream_t own = nullptr;
+    if (!s) {
+        if (h) (void)hipSetDevice(h->cfg.device);
+        HIP_TRY(hipStreamCreate(&own));
+        s = own;
+    }
+    int rc = spdm_sample_begin(h, B, d_cond, d_inpaint, inp_h, inpaint_per_sample, d_xT, d_noise, seed, sample_offset, d_history, s);
+    if (rc == SPDM_OK) rc = spdm_sample_run(h, 0, h->n_steps, s);
+    if (rc == SPDM_OK) rc = spdm_sample_result(h, d_out, s);
+    if (own) {
+        hipError_t e = hipStreamSynchronize(own);
+        (void)hipStreamDestroy(own);
+        if (rc == SPDM_OK && e != hipSuccess) rc = fail(SPDM_ERR_HIP, "stream sync: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+
+extern "C" int spdm_debug_tensor(spdm_handle* h, const char* name, float* d_out, size_t cap, int32_t shape[4]) {
+    if (!h || !name || !shape) return fail(SPDM_ERR_INVALID, "null argument");
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return fail(SPDM_ERR_MISSING, "no intermediate named '%s' (handle needs SPDM_FLAG_DEBUG_KEEP and a prior spdm_unet_forward)", name);
+    const Tensor& t = it->second;
+    const int l = t.level;
+    shape[0] = h->tapB; shape[1] = h->Hp >> l; shape[2] = h->Wp >> l; shape[3] = t.C;
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2] * shape[3];
+    if (d_out) {
+        if (cap < n) return fail(SPDM_ERR_INVALID, "buffer too small: need %zu floats", n);
+        HIP_TRY(hipMemcpy(d_out, t.p, n * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    return SPDM_OK;
+}
+
+extern "C" int spdm_profile_enable(spdm_handle* h, int32_t on) {
+    if (!h) return fail(SPDM_ERR_INVALID, "null handle");
+    h->prof = on != 0;
+    for (auto& e : h->prof_evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    h->prof_evts.clear();
+    h->prof_launches = 0; h->prof_ms = 0.0; h->prof_flops = 0.0;
+    return SPDM_OK;
+}
+
+extern "C" int spdm_profile_read(spdm_handle* h, int64_t* launches, double* total_ms, double* total_flops) {
+    if (!h) return fail(SPDM_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& e : h->prof_evts) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            h->prof_ms += ms; h->prof_flops += e.flops; h->prof_launches += 1;
+        }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    h->prof_evts.clear();
+    if (launches) *launches = h->prof_launches;
+    if (total_ms) *total_ms = h->prof_ms;
+    if (total_flops) *total_flops = h->prof_flops;
+    return SPDM_OK;
+}
