@@ -693,9 +693,9 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
                                h->lh, h->lw, c.s), "conv_in");
     Value x1 = c.conv(v0, h->inc.second, 0, /*gelu=*/true, h->inc.gamma, h->inc.beta);   // x1 = GN(raw), pending
     c.free(v0);
-    if (h->arena.keep && !c.dry && !c.err) {
+    if (h->arena.keep) {
         Tensor m = c.talloc(64, 0);
-        c.check(launch_gn_apply(c.asrc(x1), m.p, B, c.HWl(0), c.s), "gn_apply");
+        if (!c.dry && !c.err) c.check(launch_gn_apply(c.asrc(x1), m.p, B, c.HWl(0), c.s), "gn_apply");
         c.tap("x1", m);
     }
 
@@ -727,9 +727,9 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
     Value b1 = c.double_conv(cur, h->bot[0], 3);
     Value b2 = c.double_conv(b1, h->bot[1], 3);
     Value x5 = c.double_conv(b2, h->bot[2], 3);         // pending GN
-    if (h->arena.keep && !c.dry && !c.err) {
+    if (h->arena.keep) {
         Tensor m = c.talloc(256, 3);
-        c.check(launch_gn_apply(c.asrc(x5), m.p, B, c.HWl(3), c.s), "gn_apply");
+        if (!c.dry && !c.err) c.check(launch_gn_apply(c.asrc(x5), m.p, B, c.HWl(3), c.s), "gn_apply");
         c.tap("x5", m);
     }
     // ---- decoder: up1..3 (+ sa4..6) ----
