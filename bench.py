@@ -43,6 +43,31 @@ def parse():
     return p.parse_args()
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use: min(affinity mask, cgroup CPU quota).  On the GPU
+    box the affinity mask shows all 256 hardware threads but the container's share is 16 CPUs;
+    running 256 torch threads against a 16-CPU quota measures throttling, not the CPU."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(args, sd, cond_dim):
     """The oracle (torch-CPU restatement of the reference path) timed on this box's host cores on a
     bounded sample of the same workload: same geometry, batch `cpu_batch`, as many full denoise
@@ -50,11 +75,7 @@ def cpu_baseline(args, sd, cond_dim):
     import torch
     from oracle.scheduler_ref import LinearBetaSchedule, ddpm_step, ddim_step
     from oracle.unet_film_ref import unet_film_forward
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     B, H, D = args.cpu_batch, args.horizon, args.state_dim
     g = torch.Generator().manual_seed(1)

@@ -58,6 +58,7 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension has not been built "
             "(run `python -m state_policy_diffusionmodel_amd.build`); there is no CPU fallback")
+    import torch  # noqa: F401  -- FIRST: the library binds to the HIP runtime instance torch has loaded
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         try:

@@ -59,7 +59,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    # Link against the HIP runtime that PyTorch-ROCm itself loads (torch/lib/libamdhip64.so), NOT the
+    # system /opt/rocm one hipcc would add: device pointers and hipStream_t handles cross the C ABI from
+    # torch, so both sides must live in the same runtime instance (same rule torch's cpp_extension follows).
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    if not os.path.exists(os.path.join(tlib, "libamdhip64.so")):
+        raise RuntimeError(f"{tlib}/libamdhip64.so not found: this build expects PyTorch-ROCm")
+    cxx = shutil.which("g++") or shutil.which("c++")
+    cmd = [cxx, "-shared", "-fPIC", "-o", LIB, *objs, f"-L{tlib}", "-lamdhip64", f"-Wl,-rpath,{tlib}",
+           "-Wl,--no-undefined"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

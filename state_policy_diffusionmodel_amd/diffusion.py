@@ -1,0 +1,223 @@
+"""Host-side mirror of the reference's sampler objects for the hot path:
+``Diffusion_DDPM`` (``/root/reference/models/diffusion_ddpm.py:22-88, 216-277, 283-348``) and
+``Diffusion_DDIM`` (``models/diffusion_ddim.py:19-74``).
+
+Same constructor keywords, same attributes a caller touches (``noise_scheduler``,
+``noise_steps``, ``noise_estimator``, ``obs_horizon``, ``pred_horizon``, ``inpaint_horizon``,
+``prediction_dim``, ``vision_encoder``), same ``sample(batch, option)`` signature and return
+types -- so ``generate.py``'s idiom
+
+    model.noise_scheduler = DDIMScheduler(num_train_timesteps=100, ...)   # generate.py:28-34
+    model.noise_steps = 100                                               # generate.py:35
+    history = model.sample(batch=obs, option='sample_history')            # generate.py:73-76
+
+works unchanged.  What runs underneath is libspdm_hip.so (no torch compute in the loop).
+Training, validation plots and the Lightning plumbing are out of scope.
+
+Explicit, non-breaking extensions: ``sample(..., x_T=, noise=, batched=, seed=)`` for
+fixed-noise parity runs and for B > 1 independent trajectories (the reference hard-wires
+B = 1 by taking ``obs_cond[0]``, ``models/diffusion_ddpm.py:246``).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from .engine import SpdmEngine
+from .schedulers import DDIMScheduler, DDPMScheduler, _LinearBetaScheduler
+from .weights import random_state_dict, state_dict_to_numpy
+
+
+def _as_spec(sched) -> _LinearBetaScheduler:
+    """Accept our own scheduler objects, or a diffusers-like one (duck-typed on class name and
+    ``config``), as ``generate.py`` may assign either."""
+    if isinstance(sched, _LinearBetaScheduler):
+        return sched
+    name = type(sched).__name__
+    cfg = getattr(sched, "config", None)
+    T = getattr(cfg, "num_train_timesteps", None) if cfg is not None else None
+    if T is None:
+        raise TypeError(f"cannot interpret noise_scheduler of type {name}")
+    kw = dict(num_train_timesteps=int(T), beta_start=float(getattr(cfg, "beta_start", 1e-4)),
+              beta_end=float(getattr(cfg, "beta_end", 0.02)),
+              beta_schedule=getattr(cfg, "beta_schedule", "linear"),
+              clip_sample=bool(getattr(cfg, "clip_sample", False)),
+              prediction_type=getattr(cfg, "prediction_type", "epsilon"))
+    if "DDIM" in name:
+        return DDIMScheduler(**kw)
+    if "DDPM" in name:
+        return DDPMScheduler(**kw)
+    raise TypeError(f"unsupported scheduler class {name} (DDPM / DDIM only)")
+
+
+class NoiseEstimator:
+    """``self.noise_estimator`` of the reference (``UNet_Film(...)`` built at
+    models/diffusion_ddpm.py:76-82): holds the weights; calling it evaluates the HIP U-Net."""
+
+    def __init__(self, owner: "Diffusion_DDPM", state_dict):
+        self._owner = owner
+        self._sd = state_dict_to_numpy(state_dict)
+
+    def state_dict(self):
+        return {k: torch.from_numpy(v) for k, v in self._sd.items()}
+
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        eng = self._owner._engine_for(x.shape[0], x.shape[-2], x.shape[-1])
+        return eng.unet_forward(x, t, y)
+
+
+class Diffusion_DDPM:
+    def __init__(self, noise_steps: int = 1000, obs_horizon: int = 10, pred_horizon: int = 10,
+                 observation_dim: int = 2, prediction_dim: int = 2, learning_rate: float = 1e-4,
+                 model: str = "UNet", vision_encoder: Optional[Callable] = None,
+                 noise_scheduler_type: str = "linear", inpaint_horizon: int = 10, step_size: int = 1,
+                 *, state_dict=None, weight_seed: int = 0, device: int = 0, max_batch: int = 1):
+        # --- Diffusion params (models/diffusion_ddpm.py:42-48)
+        self.noise_steps = noise_steps
+        self.obs_horizon = obs_horizon
+        self.pred_horizon = pred_horizon
+        self.observation_dim = observation_dim
+        self.prediction_dim = prediction_dim
+        self.inpaint_horizon = inpaint_horizon
+        self.lr = learning_rate
+        # --- architecture switch (:54-62); the concat-conditioned 'UNet' is a different network
+        if model == "UNet_Film":
+            self.attention = True
+        elif model == "UNet_FilmnoAttention":
+            self.attention = False
+        else:
+            raise NotImplementedError("only model='UNet_Film' / 'UNet_FilmnoAttention' are on the MI355X path "
+                                      "(simple_Unet.py is out of scope, SURVEY.md section 2)")
+        # --- scheduler (:65-70); beta schedule is hard-coded 'linear' there, noise_scheduler_type unused
+        self.noise_scheduler = DDPMScheduler(num_train_timesteps=self.noise_steps, beta_schedule="linear",
+                                             clip_sample=False, prediction_type="epsilon")
+        self.cond_dim = observation_dim * obs_horizon
+        if state_dict is None:   # random-init, like constructing the reference module without a checkpoint
+            state_dict = random_state_dict(self.cond_dim, seed=weight_seed, attention=self.attention)
+        self.noise_estimator = NoiseEstimator(self, state_dict)
+        # the reference loads a private autoencoder checkpoint here (:85); any callable
+        # (N,3,96,96) -> (N,128) can be plugged in, or the batch may carry 'image_features'
+        self.vision_encoder = vision_encoder
+        self.device = torch.device("cuda", device)
+        self._device_index = device
+        self._max_batch = max_batch
+        self._engine: Optional[SpdmEngine] = None
+        self._engine_key = None
+
+    # Lightning look-alikes used by callers (generate.py:36)
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def _engine_for(self, batch: int, H: int, D: int) -> SpdmEngine:
+        spec = _as_spec(self.noise_scheduler)
+        T = max(int(spec.config.num_train_timesteps), int(self.noise_steps))
+        key = (H, D, T)
+        if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = SpdmEngine(H, D, self.cond_dim, max_batch=max(batch, self._max_batch),
+                                      device=self._device_index, attention=self.attention,
+                                      num_train_timesteps=T)
+            self._engine.load_state_dict(self.noise_estimator._sd)
+            self._engine_key = key
+        return self._engine
+
+    def add_constraints(self, x_t: torch.Tensor, x_inpaint: torch.Tensor) -> torch.Tensor:
+        """models/diffusion_ddpm.py:216-219 (in place, broadcast over the batch)."""
+        x_t[:, :, :self.inpaint_horizon, :] = x_inpaint
+        return x_t
+
+    # ==================== Sampling (models/diffusion_ddpm.py:223-277) ====================
+    def sample(self, batch: Dict[str, torch.Tensor], option: Optional[str] = None, *,
+               x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+               batched: bool = False, seed: int = 0, sample_offset: int = 0):
+        for key, tensor in batch.items():
+            batch[key] = tensor.to(self.device)
+        obs_cond = self.prepare_obs_cond_vectors(batch)                       # (B, obs_h, obs_dim)
+        inpaint = self.prepare_inpaint_vectors(batch)                         # (B, inp_h, pred_dim)
+        if not batched:                                                       # reference: B forced to 1
+            obs_cond, inpaint = obs_cond[0:1], inpaint[0:1]
+        obs_cond = obs_cond.unsqueeze(1)                                      # (B,1,obs_h,obs_dim)
+        inpaint = inpaint.unsqueeze(1)                                        # (B,1,inp_h,pred_dim)
+        B = obs_cond.shape[0]
+        H, D = self.pred_horizon + self.inpaint_horizon, self.prediction_dim
+        if x_T is None:
+            x_T = torch.rand(B, 1, H, D, device=self.device)                  # uniform, :252
+        spec = _as_spec(self.noise_scheduler)
+        spec.set_timesteps(self.noise_steps)                                  # :257/:268
+        eng = self._engine_for(B, H, D)
+        eng.set_scheduler(spec)
+        want_hist = (option == "sample_history")
+        res = eng.sample(obs_cond, x_T, noise=noise, inpaint=inpaint if self.inpaint_horizon > 0 else None,
+                         seed=seed, sample_offset=sample_offset, history=want_hist)
+        if want_hist:
+            _, hist = res
+            return [hist[i] for i in range(hist.shape[0])]                    # list of N+1 (B,1,H,D), :256-265
+        return res
+
+    # ==================== Helper functions (models/diffusion_ddpm.py:283-348) ====================
+    def prepare_observation_batch(self, batch):
+        out = {}
+        for k in ("image", "position", "action", "velocity", "image_features"):
+            if k in batch:
+                out[k] = batch[k][:, :self.obs_horizon].to(self.device).float()
+        return out
+
+    def prepare_obs_cond_vectors(self, observation_batch):
+        if "obs_cond" in observation_batch:
+            return observation_batch["obs_cond"].float()
+        if "image_features" in observation_batch:
+            feats = observation_batch["image_features"]
+        else:
+            if self.vision_encoder is None:
+                raise RuntimeError("batch has raw images but no vision_encoder was supplied "
+                                   "(the reference's autoencoder checkpoint is not part of the repo)")
+            img = observation_batch["image"]
+            with torch.no_grad():
+                enc = self.vision_encoder(img.flatten(end_dim=1))
+            feats = enc.reshape(*img.shape[:2], -1)
+        return torch.cat([observation_batch["position"], observation_batch["action"],
+                          observation_batch["velocity"], feats], dim=-1)
+
+    def prepare_inpaint_vectors(self, observation_batch):
+        if "inpaint" in observation_batch:
+            return observation_batch["inpaint"].float()
+        if self.inpaint_horizon == 0:
+            B = next(iter(observation_batch.values())).shape[0]
+            return torch.zeros(B, 0, self.prediction_dim, device=self.device)
+        pos = observation_batch["position"][:, -self.inpaint_horizon:, :]
+        act = observation_batch["action"][:, -self.inpaint_horizon:, :]
+        return torch.cat([pos, act], dim=-1)
+
+    # training-side entry points of the reference that are NOT on the sampling path
+    def training_step(self, *a, **k):
+        raise NotImplementedError("training is out of scope of the MI355X hot path (SURVEY.md section 3.5)")
+
+    validation_step = training_step
+
+
+class Diffusion_DDIM(Diffusion_DDPM):
+    """models/diffusion_ddim.py:19-74: a byte-identical copy of the DDPM loop; it becomes DDIM only
+    because the caller swaps ``noise_scheduler`` (generate.py:28-35).  Nothing to override here."""
+    pass
+
+
+def load_model(model_name: str, state_dict=None, num_of_ddim_steps: int = 100, **hparams):
+    """generate.py:23-37, minus Lightning's checkpoint reader: build the sampler and, for DDIM,
+    overwrite scheduler and noise_steps exactly as the reference's loader does."""
+    if model_name == "DDPM":
+        model = Diffusion_DDPM(state_dict=state_dict, **hparams)
+    elif model_name == "DDIM":
+        model = Diffusion_DDIM(state_dict=state_dict, **hparams)
+        model.noise_scheduler = DDIMScheduler(num_train_timesteps=num_of_ddim_steps, beta_schedule="linear",
+                                              clip_sample=False, prediction_type="epsilon")
+        model.noise_steps = num_of_ddim_steps
+    else:
+        raise ValueError("model_name must be 'DDPM' or 'DDIM'")
+    model.eval()
+    return model

@@ -1,0 +1,265 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against
+ (1) the committed golden vectors produced from the IMPORTED reference U-Net,
+ (2) the oracle (oracle/*.py) on fresh seeded inputs,
+ (3) size-independent properties at BASELINE.json's full batch (4096).
+Tolerance: 1e-4 absolute, fp32 -- the bound BASELINE.json's north_star states."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import philox_ref
+from oracle.scheduler_ref import sample_loop
+from oracle.unet_film_ref import unet_film_forward
+from state_policy_diffusionmodel_amd.weights import blob_sha256, random_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+UNET_FILES = sorted(glob.glob(os.path.join(GOLDEN, "unet_*.npz")))
+TRAJ_FILES = sorted(glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
+TAPS = {"inc": "x1", "down1": "d1", "sa1": "x2", "down2": "d2", "sa2": "x3", "down3": "d3", "sa3": "x4",
+        "bot3": "x5", "up1": "u1", "sa4": "a4", "up2": "u2", "sa5": "a5", "up3": "u3", "sa6": "a6"}
+_SD = {}
+
+
+def weights(cond_dim, seed, attention=True, sha=None):
+    key = (cond_dim, seed, attention)
+    if key not in _SD:
+        _SD[key] = random_state_dict(cond_dim, seed=seed, attention=attention)
+        if sha is not None:
+            assert blob_sha256(_SD[key]) == sha, "weight generator drifted from the fixtures"
+    return _SD[key]
+
+
+def make_engine(H, D, cond_dim, B, sd, attention=True, T=1000, debug=False):
+    from state_policy_diffusionmodel_amd.engine import SpdmEngine
+    eng = SpdmEngine(H, D, cond_dim, max_batch=B, attention=attention, num_train_timesteps=T, debug=debug)
+    eng.load_state_dict(sd)
+    return eng
+
+
+def test_native_library_is_the_one_loaded():
+    from state_policy_diffusionmodel_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libspdm_hip.so" in maps
+
+
+@pytest.mark.parametrize("path", UNET_FILES, ids=[os.path.basename(p) for p in UNET_FILES])
+def test_unet_matches_reference_golden(path):
+    g = np.load(path)
+    H, D, B = int(g["H"]), int(g["D"]), int(g["B"])
+    cond_dim = int(g["obs_h"]) * int(g["obs_dim"])
+    attention = bool(int(g["attention"]))
+    sd = weights(cond_dim, int(g["wseed"]), attention, str(g["weights_sha256"]))
+    has_taps = any(k.startswith("tap_") for k in g.files)
+    eng = make_engine(H, D, cond_dim, B, sd, attention, debug=has_taps)
+    x, cond = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["cond"]).cuda()
+    try:
+        for t, want in zip(g["t"], g["eps"]):
+            got = eng.unet_forward(x, np.atleast_1d(t), cond).cpu().numpy()
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= TOL, (path, t)
+        if has_taps:
+            eng.unet_forward(x, np.atleast_1d(g["t"][0]), cond)
+            for ref_name, mine in TAPS.items():
+                if "tap_" + ref_name in g.files and (attention or not ref_name.startswith("sa")):
+                    d = np.abs(eng.debug_tensor(mine).cpu().numpy() - g["tap_" + ref_name]).max()
+                    assert d <= TOL, (ref_name, d)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("H,D,B,attention,cond", [(24, 4, 5, True, True), (8, 1, 3, True, True),
+                                                  (48, 8, 2, False, True), (16, 3, 4, True, False),
+                                                  (32, 3, 33, True, True)])
+def test_unet_matches_oracle_on_fresh_inputs(H, D, B, attention, cond):
+    obs_h, obs_dim = 3, 11
+    sd = weights(obs_h * obs_dim, 21, attention)
+    g = torch.Generator().manual_seed(H * 1000 + D * 10 + B)
+    x = torch.randn(B, 1, H, D, generator=g) * 1.5
+    y = torch.randn(B, 1, obs_h, obs_dim, generator=g) if cond else None
+    eng = make_engine(H, D, obs_h * obs_dim, B, sd, attention)
+    try:
+        for t in (torch.tensor([17]), (torch.arange(B) * 37) % 1000):
+            want = unet_film_forward(sd, x, t, y, attention=attention).numpy()
+            got = eng.unet_forward(x.cuda(), t, None if y is None else y.cuda()).cpu().numpy()
+            assert np.abs(got - want).max() <= TOL
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("path", TRAJ_FILES, ids=[os.path.basename(p) for p in TRAJ_FILES])
+def test_sampling_loop_matches_golden_trajectories(path):
+    from state_policy_diffusionmodel_amd.schedulers import DDIMScheduler, DDPMScheduler
+    g = np.load(path)
+    kind, T, N = str(g["kind"]), int(g["T"]), int(g["N"])
+    H, D, B = int(g["H"]), int(g["D"]), int(g["B"])
+    cond_dim = int(g["obs_h"]) * int(g["obs_dim"])
+    sd = weights(cond_dim, int(g["wseed"]), True, str(g["weights_sha256"]))
+    eng = make_engine(H, D, cond_dim, B, sd, T=T)
+    try:
+        sched = (DDPMScheduler if kind == "ddpm" else DDIMScheduler)(num_train_timesteps=T)
+        sched.set_timesteps(N)
+        eng.set_scheduler(sched)
+        inpaint = torch.from_numpy(g["inpaint"]).cuda() if "inpaint" in g.files else None
+        noise = torch.from_numpy(g["noise"]).cuda() if kind == "ddpm" else None
+        x0, hist = eng.sample(torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["x_T"]).cuda(), noise=noise,
+                              inpaint=inpaint, history=True)
+        hist = hist.cpu().numpy()
+        assert hist.shape == g["history"].shape
+        per_step = np.abs(hist - g["history"]).reshape(hist.shape[0], -1).max(axis=1)
+        assert per_step.max() <= TOL, per_step                 # every intermediate iterate, not only x_0
+        np.testing.assert_array_equal(x0.cpu().numpy(), hist[-1])
+        if inpaint is not None:                                  # add_constraints: exact overwrite
+            k = int(g["inp_h"])
+            np.testing.assert_array_equal(hist[1:, :, :, :k, :], np.broadcast_to(g["inpaint"], hist[1:, :, :, :k, :].shape))
+    finally:
+        eng.close()
+
+
+def test_long_ddpm_chain_against_oracle():
+    """100-step DDPM (BASELINE configs[0] geometry: batch 1, horizon 16, state_dim 3, 100 steps) against the
+    oracle loop on this box, every iterate."""
+    from state_policy_diffusionmodel_amd.schedulers import DDPMScheduler
+    T = 100
+    B, H, D, obs_h, obs_dim = 1, 16, 3, 10, 135
+    sd = weights(obs_h * obs_dim, 0)
+    g = torch.Generator().manual_seed(5)
+    cond = torch.randn(B, 1, obs_h, obs_dim, generator=g)
+    x_T = torch.rand(B, 1, H, D, generator=g)
+    noise = torch.randn(T, B, 1, H, D, generator=g)
+    inpaint = torch.rand(B, 1, 1, D, generator=g) * 2 - 1
+    want = sample_loop(lambda x, t, y: unet_film_forward(sd, x, t, y), "ddpm", T, T, cond, x_T, noise, inpaint, history=True)
+    eng = make_engine(H, D, obs_h * obs_dim, B, sd, T=T)
+    try:
+        s = DDPMScheduler(num_train_timesteps=T)
+        s.set_timesteps(T)
+        eng.set_scheduler(s)
+        _, hist = eng.sample(cond.cuda(), x_T.cuda(), noise=noise.cuda(), inpaint=inpaint.cuda(), history=True)
+        err = (hist.cpu() - torch.stack(want)).abs().reshape(T + 1, -1).max(dim=1).values
+        assert float(err.max()) <= TOL, err
+    finally:
+        eng.close()
+
+
+def test_builtin_schedule_equals_installed_tables():
+    from state_policy_diffusionmodel_amd.schedulers import DDIMScheduler
+    B, H, D, cd = 2, 16, 3, 14
+    sd = weights(cd, 5)
+    g = torch.Generator().manual_seed(9)
+    cond, x_T = torch.randn(B, 1, 2, 7, generator=g).cuda(), torch.rand(B, 1, H, D, generator=g).cuda()
+    eng = make_engine(H, D, cd, B, sd, T=50)
+    try:
+        s = DDIMScheduler(num_train_timesteps=50)
+        s.set_timesteps(10)
+        eng.set_scheduler(s)
+        a = eng.sample(cond, x_T).cpu()
+        eng.set_builtin_schedule(1, 50, 10)
+        b = eng.sample(cond, x_T).cpu()
+        assert float((a - b).abs().max()) <= 1e-4
+    finally:
+        eng.close()
+
+
+def test_batch_independence_and_determinism():
+    """B independent trajectories == B single runs (the reference hard-wires B = 1), bit for bit,
+    and two identical calls give identical bits."""
+    B, H, D, cd = 6, 32, 3, 33
+    sd = weights(cd, 21)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 1, H, D, generator=g).cuda()
+    y = torch.randn(B, 1, 3, 11, generator=g).cuda()
+    eng = make_engine(H, D, cd, B, sd)
+    try:
+        full = eng.unet_forward(x, [3], y).cpu()
+        again = eng.unet_forward(x, [3], y).cpu()
+        assert torch.equal(full, again)
+        for b in (0, 3, 5):
+            one = eng.unet_forward(x[b:b + 1], [3], y[b:b + 1]).cpu()
+            assert torch.equal(one[0], full[b])
+    finally:
+        eng.close()
+
+
+def test_device_philox_stream_matches_oracle_and_is_shard_invariant():
+    from state_policy_diffusionmodel_amd.schedulers import DDPMScheduler
+    T, B, H, D, cd = 6, 8, 16, 3, 14
+    sd = weights(cd, 5)
+    g = torch.Generator().manual_seed(11)
+    cond, x_T = torch.randn(B, 1, 2, 7, generator=g), torch.rand(B, 1, H, D, generator=g)
+    noise = np.stack([philox_ref.step_noise(1234, i, 0, B, H * D) for i in range(T)]).reshape(T, B, 1, H, D)
+    want = sample_loop(lambda x, t, y: unet_film_forward(sd, x, t, y), "ddpm", T, T, cond, x_T,
+                       torch.from_numpy(noise), None)
+    eng = make_engine(H, D, cd, B, sd, T=T)
+    try:
+        s = DDPMScheduler(num_train_timesteps=T)
+        s.set_timesteps(T)
+        eng.set_scheduler(s)
+        got = eng.sample(cond.cuda(), x_T.cuda(), noise=None, seed=1234).cpu()
+        assert float((got - want).abs().max()) <= TOL
+        # a "rank" that owns global trajectories 5..7 reproduces them exactly
+        part = eng.sample(cond[5:].cuda(), x_T[5:].cuda(), noise=None, seed=1234, sample_offset=5).cpu()
+        assert torch.equal(part, got[5:])
+    finally:
+        eng.close()
+
+
+def test_full_size_batch_properties():
+    """BASELINE.json's batch (4096, horizon 32): too large for the CPU oracle in seconds, so check
+    size-independent properties: each trajectory of the big batch equals the same trajectory run in a
+    small batch (the oracle-checked regime), inpainted rows are exact, output finite."""
+    from state_policy_diffusionmodel_amd.schedulers import DDPMScheduler
+    B, H, D, cd, T, N = 4096, 32, 3, 1350, 1000, 2
+    sd = weights(cd, 0)
+    g = torch.Generator().manual_seed(2)
+    cond = torch.randn(B, 1, 10, 135, generator=g).cuda()
+    x_T = torch.rand(B, 1, H, D, generator=g).cuda()
+    inpaint = (torch.rand(B, 1, 1, D, generator=g) * 2 - 1).cuda()
+    eng = make_engine(H, D, cd, B, sd, T=T)
+    try:
+        s = DDPMScheduler(num_train_timesteps=T)
+        s.set_timesteps(T)
+        eng.set_scheduler(s)
+        eng.sample_begin(cond, x_T, inpaint=inpaint, seed=3)
+        eng.sample_run(0, N)
+        big = eng.sample_result().cpu()
+        assert bool(torch.isfinite(big).all())
+        assert torch.equal(big[:, :, :1, :], inpaint.cpu())
+        idx = [0, 1, 2047, 4095]
+        for i in idx:
+            eng.sample_begin(cond[i:i + 1], x_T[i:i + 1], inpaint=inpaint[i:i + 1], seed=3, sample_offset=i)
+            eng.sample_run(0, N)
+            small = eng.sample_result().cpu()
+            assert float((small[0] - big[i]).abs().max()) <= 1e-5
+    finally:
+        eng.close()
+
+
+def test_error_behaviour():
+    B, H, D, cd = 2, 16, 3, 14
+    sd = weights(cd, 5)
+    eng = make_engine(H, D, cd, B, sd)
+    try:
+        x = torch.zeros(3, 1, H, D).cuda()
+        with pytest.raises(RuntimeError, match="max_batch"):
+            eng.unet_forward(x, [0], None)
+        with pytest.raises(RuntimeError, match="outside"):
+            eng.unet_forward(x[:1], [1000], None)
+        with pytest.raises(RuntimeError, match="scheduler"):
+            eng.sample(None, x[:2])
+        with pytest.raises(RuntimeError, match="already loaded"):
+            eng.load_state_dict(sd)
+    finally:
+        eng.close()
+    with pytest.raises(KeyError):
+        from state_policy_diffusionmodel_amd.engine import SpdmEngine
+        e2 = SpdmEngine(H, D, cd, max_batch=1)
+        try:
+            e2.load_state_dict({k: v for k, v in sd.items() if not k.startswith("sa3")})
+        finally:
+            e2.close()
