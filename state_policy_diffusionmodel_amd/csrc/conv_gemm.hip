@@ -32,6 +32,7 @@
 namespace spdm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 32;    // channels per K chunk
 constexpr int LDK = 36;   // padded LDS row length (floats)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
         const int m = m0 - halo + q;
         const bool v = (q < QA) && (m >= 0) && (m < M);
         aval[p] = v;
-        aptr[p] = a.src + (size_t)(v ? m : 0) * a.src_ld + c4 * 4;
+        aptr[p] = a.src + (size_t)min(max(m, 0), M - 1) * a.src_ld + c4 * 4;   // clamped: always loadable
         amean[p] = 0.f;
         arstd[p] = 1.f;
         if (pro && v) {
@@ -136,58 +137,63 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    float4 areg[APASS], wreg[WPASS];
+    // Staging registers.  Everything below is written with compile-time indices and UNCONDITIONAL
+    // loads (rows outside the tensor are clamped to a valid address and zeroed at LDS-write time):
+    // a predicated load makes hipcc wait for it right where it is issued, and arrays captured by a
+    // lambda end up in scratch -- both defeat the overlap of the loads with the MFMA block.
+    f32x4 areg[APASS], wreg[WPASS];
+    f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};   // GroupNorm gain / offset of this thread's 4 channels
 
-    auto load_A = [&](int chunk) {
-#pragma unroll
-        for (int p = 0; p < APASS; ++p) {
-            areg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (aval[p]) areg[p] = *reinterpret_cast<const float4*>(aptr[p] + chunk * CK);
-        }
-    };
-    auto store_A = [&](int chunk, int buf) {
-        float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pro) {
-            g4 = *reinterpret_cast<const float4*>(a.pro_gamma + chunk * CK + c4 * 4);
-            b4 = *reinterpret_cast<const float4*>(a.pro_beta + chunk * CK + c4 * 4);
-        }
-        float* dstb = Abuf + buf * QA * LDK + c4 * 4;
-#pragma unroll
-        for (int p = 0; p < APASS; ++p) {
-            const int q = p * 32 + srow_t;
-            float4 v = areg[p];
-            if (pro && aval[p]) {
-                const float rs = arstd[p], mu = amean[p];
-                float sx = rs * g4.x, sy = rs * g4.y, sz = rs * g4.z, sw = rs * g4.w;
-                v.x = (v.x - mu) * sx + b4.x;
-                v.y = (v.y - mu) * sy + b4.y;
-                v.z = (v.z - mu) * sz + b4.z;
-                v.w = (v.w - mu) * sw + b4.w;
-                if (pro_gelu) {
-                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-                }
-            }
-            if (q < QA) *reinterpret_cast<float4*>(dstb + q * LDK) = v;
-        }
-    };
-    auto load_W = [&](int chunk, int tap) {
-        const float* base = wptr + (size_t)tap * N * K + chunk * CK;
-#pragma unroll
-        for (int p = 0; p < WPASS; ++p) wreg[p] = *reinterpret_cast<const float4*>(base + (size_t)p * 32 * K);
-    };
-    auto store_W = [&](int buf) {
-        float* dstb = Wbuf + buf * N_T * LDK + srow_t * LDK + c4 * 4;
-#pragma unroll
-        for (int p = 0; p < WPASS; ++p) *reinterpret_cast<float4*>(dstb + p * 32 * LDK) = wreg[p];
-    };
+#define SPDM_LOAD_A(chunk_)                                                                         \
+    {                                                                                               \
+        _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_)                                       \
+            areg[p_] = *reinterpret_cast<const f32x4*>(aptr[p_] + (chunk_) * CK);                   \
+        if (pro) {                                                                                  \
+            g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + (chunk_) * CK + c4 * 4);            \
+            b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (chunk_) * CK + c4 * 4);             \
+        }                                                                                           \
+    }
+#define SPDM_LOAD_W(chunk_, tap_)                                                                   \
+    {                                                                                               \
+        const float* wb_ = wptr + (size_t)(tap_) * N * K + (chunk_) * CK;                           \
+        _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                       \
+            wreg[p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * 32 * K);                \
+    }
+#define SPDM_STORE_W(buf_)                                                                          \
+    {                                                                                               \
+        float* wd_ = Wbuf + (buf_) * N_T * LDK + srow_t * LDK + c4 * 4;                            \
+        _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                       \
+            *reinterpret_cast<f32x4*>(wd_ + p_ * 32 * LDK) = wreg[p_];                            \
+    }
+#define SPDM_STORE_A(chunk_, buf_)                                                                  \
+    {                                                                                               \
+        const f32x4 g4_ = g4r, b4_ = b4r;                                                           \
+        float* ad_ = Abuf + (buf_) * QA * LDK + c4 * 4;                                             \
+        _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                     \
+            f32x4 v_ = areg[p_];                                                                   \
+            if (pro) {                                                                              \
+                const float rs_ = arstd[p_], mu_ = amean[p_];                                       \
+                v_.x = (v_.x - mu_) * (rs_ * g4_.x) + b4_.x;                                        \
+                v_.y = (v_.y - mu_) * (rs_ * g4_.y) + b4_.y;                                        \
+                v_.z = (v_.z - mu_) * (rs_ * g4_.z) + b4_.z;                                        \
+                v_.w = (v_.w - mu_) * (rs_ * g4_.w) + b4_.w;                                        \
+                if (pro_gelu) {                                                                     \
+                    v_.x = gelu_erf(v_.x); v_.y = gelu_erf(v_.y);                                   \
+                    v_.z = gelu_erf(v_.z); v_.w = gelu_erf(v_.w);                                   \
+                }                                                                                   \
+            }                                                                                       \
+            if (!aval[p_]) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                    \
+            if (p_ * 32 + srow_t < QA) *reinterpret_cast<f32x4*>(ad_ + (p_ * 32 + srow_t) * LDK) = v_; \
+        }                                                                                           \
+    }
 
     const int nchunks = K / CK;
     const int niter = nchunks * taps;
 
-    load_A(0);
-    load_W(0, 0);
-    store_A(0, 0);
-    store_W(0);
+    SPDM_LOAD_A(0)
+    SPDM_LOAD_W(0, 0)
+    SPDM_STORE_A(0, 0)
+    SPDM_STORE_W(0)
     __syncthreads();
 
     int chunk = 0, tap = 0;
@@ -197,8 +203,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
         if (ntap == taps) { ntap = 0; nchunk = chunk + 1; }
         const bool have_next = (it + 1 < niter);
         const bool next_A = have_next && (ntap == 0);
-        if (have_next) load_W(nchunk, ntap);
-        if (next_A) load_A(nchunk);
+        // A before W: hipcc guards the re-use of the A staging registers with a vmcnt wait that would
+        // otherwise also wait for the W loads issued just before it
+        if (next_A) SPDM_LOAD_A(nchunk)
+        if (have_next) SPDM_LOAD_W(nchunk, ntap)
 
         // ---- MFMA block on Abuf[chunk&1], Wbuf[it&1] ----
         const float* Ab = Abuf + (chunk & 1) * QA * LDK;
@@ -230,12 +238,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
                 }
         }
 
-        if (have_next) store_W((it + 1) & 1);
-        if (next_A) store_A(nchunk, nchunk & 1);
+        if (have_next) SPDM_STORE_W((it + 1) & 1)
+        if (next_A) SPDM_STORE_A(nchunk, nchunk & 1)
         __syncthreads();
         tap = ntap;
         chunk = nchunk;
     }
+#undef SPDM_LOAD_A
+#undef SPDM_LOAD_W
+#undef SPDM_STORE_A
+#undef SPDM_STORE_W
 
     // ---- epilogue ----
     const int row_base = m0 + wm * MT * 32 + 4 * kh;     // + mt*32 + (r&3) + 8*(r>>2)
