@@ -68,6 +68,8 @@ typedef struct {
 } spdm_config;
 
 #define SPDM_FLAG_DEBUG_KEEP 1    /* keep every intermediate alive for spdm_debug_tensor */
+#define SPDM_FLAG_EXACT_FP32 2    /* contractions on the exact fp32 MFMA path instead of the default split-fp16
+                                    path (hi + 2^-11 lo, 3 fp16 MFMAs, fp32 accumulate); env SPDM_PREC=f32 does the same */
 
 /* One entry per tensor of the reference state_dict (names exactly as
  * UNet_Film.state_dict() gives them, e.g. "down1.cond_encoder.2.weight"),

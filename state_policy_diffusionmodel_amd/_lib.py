@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libspdm_hip.so")
 
 SPDM_DDPM, SPDM_DDIM = 0, 1
 SPDM_FLAG_DEBUG_KEEP = 1
+SPDM_FLAG_EXACT_FP32 = 2
 ABI_VERSION = 1
 
 

@@ -33,11 +33,24 @@ namespace spdm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// PREC_F32   : operands stay fp32, v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain).
+// PREC_SPLIT : every fp32 operand x is split on the fly into two fp16 numbers
+//                  hi = fp16(x),   lo = fp16((x - hi) * 2^11)            (x = hi + lo * 2^-11 to ~2^-22 |x|)
+//              and a product a*b is evaluated as  ah*bh  +  2^-11 (ah*bl + al*bh)  with three
+//              v_mfma_f32_32x32x16_f16 (fp16 x fp16 products are exact in fp32; accumulation is fp32).
+//              The dropped al*bl term is 2^-22 relative, i.e. 4 fp32 ulps per product, random sign.
+//              The fp16 matrix pipe runs 16x the fp32 one per clock, so 3 MFMAs per K=16 are 5.3x the
+//              fp32-MFMA rate.  The scaling keeps lo in fp16's normal range for |x| down to ~1e-5 * 2^-11.
+//              Weights are split once at load time (host); activations at LDS-staging time.
 
 constexpr int CK = 32;    // channels per K chunk
 constexpr int LDK = 36;   // padded LDS row length (floats)
+enum { PREC_F32 = 0, PREC_SPLIT = 1 };
 
-template <bool HALO, int WM, int WN, int MT, int NT>
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
     constexpr int APASS = HALO ? (M_T + 18 + 31) / 32 : M_T / 32;   // halo <= 9 rows each side (W <= 8)
@@ -59,10 +72,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
     const int mtile = logical / n_ntiles, ntile = logical - mtile * n_ntiles;
     const int m0 = mtile * M_T, n0 = ntile * N_T;
 
-    float* Abuf = smem;                       // [2][QA][LDK]
-    float* Wbuf = Abuf + 2 * QA * LDK;        // [2][N_T][LDK]
+    const int QZ = QA + 1;                    // + one all-zero row: what a masked (out-of-image) tap reads
+    float* Abuf = smem;                       // [2][QZ][LDK]
+    float* Wbuf = Abuf + 2 * QZ * LDK;        // [2][N_T][LDK]
     float* smean = Wbuf + 2 * N_T * LDK;      // [NSP]
     float* srstd = smean + NSP;               // [NSP]
+
+    if (tid < 2 * LDK) Abuf[(tid / LDK) * QZ * LDK + QA * LDK + tid % LDK] = 0.f;
 
     // ---- prologue statistics of the samples this slab touches ----
     const bool pro = (a.pro != PRO_NONE);
@@ -104,13 +120,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
     const float* wptr = a.wgt + (size_t)(n0 + srow_t) * K + c4 * 4;   // + (tap*N + p*32)*K + chunk*32
 
     // ---- per-lane fragment rows and tap masks ----
+    // A lane reads row (r + halo + shift(tap)) of the slab, or the all-zero row when the tap falls
+    // outside the image / the sample for its output position.
     int aoff[MT], boff[NT];
     unsigned amask[MT];
+    const int koff = kh * 4;    // floats: 16 B per lane half in both slab formats
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int r = wm * MT * 32 + mt * 32 + li;
-        aoff[mt] = (r + halo) * LDK + kh * 4;
-        unsigned mask = 0;
+        aoff[mt] = (r + halo) * LDK + koff;
+        unsigned mask = HALO ? 0u : 1u;
         if (HALO) {
             const int m = m0 + r;
             if (m < M) {
@@ -126,21 +145,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
         }
         amask[mt] = mask;
     }
+    const int zoff = QA * LDK + koff;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) boff[nt] = (wn * NT * 32 + nt * 32 + li) * LDK + kh * 4;
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = (wn * NT * 32 + nt * 32 + li) * LDK + koff;
 
-    f32x16 acc[MT][NT];
+    constexpr int NACC = (PREC == PREC_SPLIT) ? 2 : 1;     // [1]: the 2^-11-scaled cross terms
+    f32x16 acc[NACC][MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int c = 0; c < NACC; ++c)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][mt][nt][r] = 0.f;
 
     // Staging registers.  Everything below is written with compile-time indices and UNCONDITIONAL
     // loads (rows outside the tensor are clamped to a valid address and zeroed at LDS-write time):
-    // a predicated load makes hipcc wait for it right where it is issued, and arrays captured by a
-    // lambda end up in scratch -- both defeat the overlap of the loads with the MFMA block.
+    // a predicated load makes hipcc wait for it right where it is issued, and HIP's float4 struct
+    // arrays end up in scratch -- both defeat the overlap of the loads with the MFMA block.
     f32x4 areg[APASS], wreg[WPASS];
     f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};   // GroupNorm gain / offset of this thread's 4 channels
 
@@ -157,20 +180,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
     {                                                                                               \
         const float* wb_ = wptr + (size_t)(tap_) * N * K + (chunk_) * CK;                           \
         _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                       \
-            wreg[p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * 32 * K);                \
+            wreg[p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * 32 * K);                  \
     }
 #define SPDM_STORE_W(buf_)                                                                          \
     {                                                                                               \
-        float* wd_ = Wbuf + (buf_) * N_T * LDK + srow_t * LDK + c4 * 4;                            \
+        float* wd_ = Wbuf + (buf_) * N_T * LDK + srow_t * LDK + c4 * 4;                             \
         _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                       \
-            *reinterpret_cast<f32x4*>(wd_ + p_ * 32 * LDK) = wreg[p_];                            \
+            *reinterpret_cast<f32x4*>(wd_ + p_ * 32 * LDK) = wreg[p_];                              \
     }
+    // fp32 slab row: 32 floats.  split slab row: [32 x fp16 hi | 32 x fp16 lo] (same 128 bytes).
 #define SPDM_STORE_A(chunk_, buf_)                                                                  \
     {                                                                                               \
         const f32x4 g4_ = g4r, b4_ = b4r;                                                           \
-        float* ad_ = Abuf + (buf_) * QA * LDK + c4 * 4;                                             \
+        float* ad_ = Abuf + (buf_) * QZ * LDK;                                                      \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                     \
-            f32x4 v_ = areg[p_];                                                                   \
+            f32x4 v_ = areg[p_];                                                                    \
             if (pro) {                                                                              \
                 const float rs_ = arstd[p_], mu_ = amean[p_];                                       \
                 v_.x = (v_.x - mu_) * (rs_ * g4_.x) + b4_.x;                                        \
@@ -182,8 +206,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
                     v_.z = gelu_erf(v_.z); v_.w = gelu_erf(v_.w);                                   \
                 }                                                                                   \
             }                                                                                       \
-            if (!aval[p_]) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                    \
-            if (p_ * 32 + srow_t < QA) *reinterpret_cast<f32x4*>(ad_ + (p_ * 32 + srow_t) * LDK) = v_; \
+            if (!aval[p_]) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+            if (p_ * 32 + srow_t < QA) {                                                            \
+                float* row_ = ad_ + (p_ * 32 + srow_t) * LDK;                                       \
+                if (PREC == PREC_SPLIT) {                                                           \
+                    f16x4 hi_, lo_;                                                                 \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                             \
+                        const _Float16 h_ = (_Float16)v_[e_];                                       \
+                        hi_[e_] = h_;                                                               \
+                        lo_[e_] = (_Float16)((v_[e_] - (float)h_) * 2048.0f);                       \
+                    }                                                                               \
+                    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(row_) + c4 * 4) = hi_;     \
+                    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(row_) + 32 + c4 * 4) = lo_; \
+                } else {                                                                            \
+                    *reinterpret_cast<f32x4*>(row_ + c4 * 4) = v_;                                  \
+                }                                                                                   \
+            }                                                                                       \
         }                                                                                           \
     }
 
@@ -209,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
         if (have_next) SPDM_LOAD_W(nchunk, ntap)
 
         // ---- MFMA block on Abuf[chunk&1], Wbuf[it&1] ----
-        const float* Ab = Abuf + (chunk & 1) * QA * LDK;
+        const float* Ab = Abuf + (chunk & 1) * QZ * LDK;
         const float* Wb = Wbuf + (it & 1) * N_T * LDK;
         int shift = 0;
         if (HALO) {
@@ -217,25 +255,52 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
             const int dw = (taps == 9) ? tap % 3 - 1 : 0;
             shift = (dh * W + dw) * LDK;
         }
+        const float* ap[MT];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 av[MT], bv[NT];
+        for (int mt = 0; mt < MT; ++mt) ap[mt] = Ab + (((amask[mt] >> tap) & 1u) ? aoff[mt] + shift : zoff);
+
+        if (PREC == PREC_SPLIT) {
+            // row = [hi: 32 fp16 | lo: 32 fp16]; K=16 step s, lane half kh: 8 fp16 at byte 32 s + 16 kh
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                av[mt] = *reinterpret_cast<const float4*>(Ab + aoff[mt] + shift + g * 8);
-                if (HALO && !((amask[mt] >> tap) & 1u)) av[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(Wb + boff[nt] + g * 8);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    ah[mt] = *reinterpret_cast<const f16x8*>(ap[mt] + s2 * 8);
+                    al[mt] = *reinterpret_cast<const f16x8*>(ap[mt] + 16 + s2 * 8);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+                    bh[nt] = *reinterpret_cast<const f16x8*>(Wb + boff[nt] + s2 * 8);
+                    bl[nt] = *reinterpret_cast<const f16x8*>(Wb + boff[nt] + 16 + s2 * 8);
                 }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[0][mt][nt], 0, 0, 0);
+                        acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[NACC - 1][mt][nt], 0, 0, 0);
+                        acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[NACC - 1][mt][nt], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + g * 8);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(Wb + boff[nt] + g * 8);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[0][mt][nt], 0, 0, 0);
+                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[0][mt][nt], 0, 0, 0);
+                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[0][mt][nt], 0, 0, 0);
+                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[0][mt][nt], 0, 0, 0);
+                    }
+            }
         }
 
         if (have_next) SPDM_STORE_W((it + 1) & 1)
@@ -248,6 +313,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
 #undef SPDM_LOAD_W
 #undef SPDM_STORE_A
 #undef SPDM_STORE_W
+
+    if (PREC == PREC_SPLIT) {   // fold the scaled cross terms in: x = hi*hi + 2^-11 (hi*lo + lo*hi)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[0][mt][nt][r] = acc[0][mt][nt][r] + acc[NACC - 1][mt][nt][r] * (1.0f / 2048.0f);
+    }
 
     // ---- epilogue ----
     const int row_base = m0 + wm * MT * 32 + 4 * kh;     // + mt*32 + (r&3) + 8*(r>>2)
@@ -267,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float v = acc[mt][nt][4 * g + j];
+                            const float v = acc[0][mt][nt][4 * g + j];
                             s1 += v;
                             s2 += v * v;
                         }
@@ -283,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const float v = acc[mt][nt][4 * g + j];
+                            const float v = acc[0][mt][nt][4 * g + j];
                             s1 += v;
                             s2 += v * v;
                         }
@@ -329,7 +404,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
             for (int r = 0; r < 16; ++r) {
                 const int row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
                 if (row < M) {
-                    float v = acc[mt][nt][r] + bias;
+                    float v = acc[0][mt][nt][r] + bias;
                     if (a.epi == EPI_BIAS_GELU) v = gelu_erf(v);
                     if (a.epi == EPI_BIAS_RESID) v += a.resid[(size_t)row * a.resid_ld + col];
                     a.dst[(size_t)row * a.dst_ld + col] = v;
@@ -351,14 +426,14 @@ GemmGeom gemm_geometry(int M, int N, int HW) {
 
 double gemm_flops(const GemmArgs& a) { return 2.0 * (double)a.M * (double)a.N * (double)a.K * (double)a.taps; }
 
-template <bool HALO, int WM, int WN, int MT, int NT>
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT>
 static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
     const int halo = HALO ? a.W + 1 : 0;
     const int QA = M_T + 2 * halo;
     const int NSP = (QA + 4) & ~3;
-    const size_t lds = (size_t)(2 * QA * LDK + 2 * N_T * LDK + 2 * NSP) * sizeof(float);
-    auto kern = conv_gemm_kernel<HALO, WM, WN, MT, NT>;
+    const size_t lds = (size_t)(2 * (QA + 1) * LDK + 2 * N_T * LDK + 2 * NSP) * sizeof(float);
+    auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT>;
     static size_t lds_set = 0;
     if (lds > lds_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -387,12 +462,20 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if ((a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID) && a.bias == nullptr) return hipErrorInvalidValue;
     if (a.epi == EPI_BIAS_RESID && a.resid == nullptr) return hipErrorInvalidValue;
     const GemmGeom g = gemm_geometry(a.M, a.N, a.HW);
-    if (a.taps == 1) {
-        if (g.n_tile == 128) return launch_cfg<false, 2, 2, 2, 2>(a, g, s);
-        return launch_cfg<false, 2, 2, 2, 1>(a, g, s);
+    if (a.split) {
+        if (a.taps == 1) {
+            if (g.n_tile == 128) return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 2>(a, g, s);
+            return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 1>(a, g, s);
+        }
+        if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2>(a, g, s);
+        return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1>(a, g, s);
     }
-    if (g.n_tile == 128) return launch_cfg<true, 2, 2, 2, 2>(a, g, s);
-    return launch_cfg<true, 2, 2, 2, 1>(a, g, s);
+    if (a.taps == 1) {
+        if (g.n_tile == 128) return launch_cfg<false, PREC_F32, 2, 2, 2, 2>(a, g, s);
+        return launch_cfg<false, PREC_F32, 2, 2, 2, 1>(a, g, s);
+    }
+    if (g.n_tile == 128) return launch_cfg<true, PREC_F32, 2, 2, 2, 2>(a, g, s);
+    return launch_cfg<true, PREC_F32, 2, 2, 2, 1>(a, g, s);
 }
 
 }  // namespace spdm

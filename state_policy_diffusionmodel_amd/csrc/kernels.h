@@ -35,7 +35,8 @@ enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RESID = 3, EPI_P
 
 struct GemmArgs {
     const float* src;  int src_ld;     // [M][src_ld], K valid channels
-    const float* wgt;                  // [taps][N][K]  (k contiguous)
+    const float* wgt;                  // [taps][N][K]  (k contiguous); split: per 32-k chunk [32 fp16 hi | 32 fp16 lo]
+    int split;                         // 0: fp32 MFMA (exact); 1: split-fp16 MFMA (wgt in the split format)
     float* dst;        int dst_ld;
     int M, K, N;
     int taps;                          // 1, 3 (vertical taps, W == 1) or 9

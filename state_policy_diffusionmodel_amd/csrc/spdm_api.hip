@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -109,9 +110,9 @@ struct Value {             // a tensor plus the GroupNorm affine still pending o
     bool pending_gn() const { return st.valid; }
 };
 
-struct ConvW { float* w = nullptr; int taps = 0, cin = 0, cout = 0; };
+struct ConvW { float* w = nullptr; float* ws = nullptr; int taps = 0, cin = 0, cout = 0; };   // ws: split-fp16 copy
 struct DoubleConvW { ConvW first, second; float* gamma = nullptr; float* beta = nullptr; };
-struct LinW { float* w = nullptr; float* b = nullptr; int in = 0, out = 0; };
+struct LinW { float* w = nullptr; float* ws = nullptr; float* b = nullptr; int in = 0, out = 0; };
 struct ResampleW { DoubleConvW dc1, dc2; LinW emb, film; float* temb_table = nullptr; int cout = 0; };
 struct AttnW { LinW in_proj, out_proj, ff1, ff2; float* ln_g = nullptr; float* ln_b = nullptr; float* ff_ln_g = nullptr; float* ff_ln_b = nullptr; int C = 0; };
 
@@ -130,6 +131,7 @@ struct spdm_handle {
     float* outc_w = nullptr;
     float outc_b = 0.f;
     bool weights_loaded = false, temb_ready = false;
+    bool split = true;                    // split-fp16 MFMA path (default); SPDM_PREC=f32 selects the exact fp32 MFMA path
     std::vector<float> time_table;        // host (T, time_dim)
     float* d_time_silu = nullptr;         // device SiLU(pos_encoding) (T, time_dim)
     // schedule
@@ -284,6 +286,8 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
     HIP_TRY(hipSetDevice(cfg->device));
     spdm_handle* h = new spdm_handle();
     h->cfg = *cfg;
+    if (const char* pe = getenv("SPDM_PREC")) h->split = !(strcmp(pe, "f32") == 0 || strcmp(pe, "fp32") == 0);
+    if (cfg->flags & SPDM_FLAG_EXACT_FP32) h->split = false;
     // pad_to(x, 8): models/Unet_FiLmLayer.py:15-28
     const int H0 = cfg->horizon, D = cfg->state_dim;
     h->Hp = (H0 % 8) ? H0 + 8 - H0 % 8 : H0;
@@ -353,6 +357,21 @@ struct Loader {
         if (d != e->ndim || numel != e->numel || e->offset + e->numel > n) { err = fail(SPDM_ERR_INVALID, "tensor '%s': bad extent", name.c_str()); return nullptr; }
         return blob + e->offset;
     }
+    // fp32 [rows][K] -> per 32-k chunk [32 x fp16 hi | 32 x fp16 lo], lo = fp16((x - hi) * 2^11); same byte size
+    float* upload_split(const std::vector<float>& v, size_t K) {
+        if (K % 32 != 0) { err = fail(SPDM_ERR_INVALID, "split weights need K %% 32 == 0"); return nullptr; }
+        std::vector<float> out(v.size());
+        for (size_t base = 0; base < v.size(); base += 32) {
+            _Float16* hp = reinterpret_cast<_Float16*>(&out[base]);
+            for (int j = 0; j < 32; ++j) {
+                const float x = v[base + j];
+                const _Float16 hi = (_Float16)x;
+                hp[j] = hi;
+                hp[32 + j] = (_Float16)((x - (float)hi) * 2048.0f);
+            }
+        }
+        return upload(out);
+    }
     float* upload(const std::vector<float>& v) {
         void* p = nullptr;
         if (dev_alloc(h, &p, v.size() * sizeof(float)) != SPDM_OK) { err = SPDM_ERR_HIP; return nullptr; }
@@ -376,6 +395,7 @@ struct Loader {
                     v[((size_t)t * cout + o) * cin + i] = src[(((size_t)o * cin + i) * 3 + kh) * 3 + kw];
         }
         c.w = upload(v);
+        c.ws = (cin % 32 == 0) ? upload_split(v, cin) : nullptr;
         c.taps = taps; c.cin = cin; c.cout = cout;
         return c;
     }
@@ -391,6 +411,7 @@ struct Loader {
         std::vector<float> v((size_t)out * in_pad, 0.f);
         for (int o = 0; o < out; ++o) memcpy(&v[(size_t)o * in_pad], w + (size_t)o * in, sizeof(float) * in);
         l.w = upload(v);
+        l.ws = (in_pad % 32 == 0) ? upload_split(v, in_pad) : nullptr;
         l.b = vec(bname, out);
         l.in = in_pad; l.out = out;
         return l;
@@ -603,7 +624,8 @@ struct Ctx {
         out.gamma = gamma; out.beta = beta;
         if (err || dry) return out;
         GemmArgs a{};
-        a.src = in.t.p; a.src_ld = in.t.C; a.wgt = w.w; a.dst = out.t.p; a.dst_ld = w.cout;
+        a.split = (h->split && w.ws) ? 1 : 0;
+        a.src = in.t.p; a.src_ld = in.t.C; a.wgt = a.split ? w.ws : w.w; a.dst = out.t.p; a.dst_ld = w.cout;
         a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
         a.H = Hl(level); a.W = Wl(level); a.HW = HW;
         a.pro = in.pending_gn() ? (gelu ? PRO_GN_GELU : PRO_GN) : PRO_NONE;
@@ -636,7 +658,8 @@ struct Ctx {
     void linear(const float* x, int ld, int rows, const LinW& w, float* y, int epi, const float* resid) {
         if (err || dry) return;
         GemmArgs a{};
-        a.src = x; a.src_ld = ld; a.wgt = w.w; a.dst = y; a.dst_ld = w.out;
+        a.split = (h->split && w.ws) ? 1 : 0;
+        a.src = x; a.src_ld = ld; a.wgt = a.split ? w.ws : w.w; a.dst = y; a.dst_ld = w.out;
         a.M = rows; a.K = w.in; a.N = w.out; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
         a.pro = PRO_NONE; a.epi = epi; a.bias = w.b; a.resid = resid; a.resid_ld = w.out;
         check(launch_gemm(a, s), "linear GEMM");
@@ -776,7 +799,8 @@ static int ensure_temb(spdm_handle* h, hipStream_t s) {
     ResampleW* blocks[6] = {&h->down[0], &h->down[1], &h->down[2], &h->up[0], &h->up[1], &h->up[2]};
     for (int i = 0; i < 6 && e == hipSuccess; ++i) {
         GemmArgs a{};
-        a.src = h->d_time_silu; a.src_ld = dim; a.wgt = blocks[i]->emb.w; a.dst = blocks[i]->temb_table; a.dst_ld = blocks[i]->cout;
+        a.split = (h->split && blocks[i]->emb.ws) ? 1 : 0;
+        a.src = h->d_time_silu; a.src_ld = dim; a.wgt = a.split ? blocks[i]->emb.ws : blocks[i]->emb.w; a.dst = blocks[i]->temb_table; a.dst_ld = blocks[i]->cout;
         a.M = T; a.K = dim; a.N = blocks[i]->cout; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
         a.pro = PRO_NONE; a.epi = EPI_BIAS; a.bias = blocks[i]->emb.b;
         e = launch_gemm(a, s);
@@ -797,7 +821,8 @@ static int compute_film(spdm_handle* h, int B, const float* d_cond, hipStream_t 
     ResampleW* blocks[6] = {&h->down[0], &h->down[1], &h->down[2], &h->up[0], &h->up[1], &h->up[2]};
     for (int i = 0; i < 6 && e == hipSuccess; ++i) {
         GemmArgs a{};
-        a.src = h->d_condm; a.src_ld = h->film_kp; a.wgt = blocks[i]->film.w; a.dst = h->d_film[i]; a.dst_ld = 2 * blocks[i]->cout;
+        a.split = (h->split && blocks[i]->film.ws) ? 1 : 0;
+        a.src = h->d_condm; a.src_ld = h->film_kp; a.wgt = a.split ? blocks[i]->film.ws : blocks[i]->film.w; a.dst = h->d_film[i]; a.dst_ld = 2 * blocks[i]->cout;
         a.M = B; a.K = h->film_kp; a.N = 2 * blocks[i]->cout; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
         a.pro = PRO_NONE; a.epi = EPI_BIAS; a.bias = blocks[i]->film.b;
         e = launch_gemm(a, s);

@@ -33,7 +33,7 @@ def _ptr(t: Optional[torch.Tensor]):
 class SpdmEngine:
     def __init__(self, horizon: int, state_dim: int, cond_dim: int, max_batch: int, device: int = 0,
                  attention: bool = True, time_dim: int = 256, num_train_timesteps: int = 1000,
-                 debug: bool = False):
+                 debug: bool = False, exact_fp32: bool = False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("SpdmEngine needs a visible MI355X (HIP device); there is no CPU fallback")
@@ -43,7 +43,7 @@ class SpdmEngine:
         self.num_train_timesteps = int(num_train_timesteps)
         cfg = _lib.SpdmConfig(self.horizon, self.state_dim, self.cond_dim, self.time_dim, int(self.attention),
                               self.max_batch, device, self.num_train_timesteps,
-                              _lib.SPDM_FLAG_DEBUG_KEEP if debug else 0)
+                              (_lib.SPDM_FLAG_DEBUG_KEEP if debug else 0) | (_lib.SPDM_FLAG_EXACT_FP32 if exact_fp32 else 0))
         h = ctypes.c_void_p()
         _lib.check(self.lib.spdm_create(ctypes.byref(cfg), ctypes.byref(h)), "spdm_create")
         self._h = h

@@ -43,7 +43,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "unet_*.npz")
         attention = bool(int(g["attention"]))
         sd = random_state_dict(cond_dim, seed=int(g["wseed"]), attention=attention)
         t0 = time.time()
-        eng = SpdmEngine(H, D, cond_dim, max_batch=B, attention=attention, debug=True)
+        eng = SpdmEngine(H, D, cond_dim, max_batch=B, attention=attention, debug=True,
+                         exact_fp32=os.environ.get('DIAG_EXACT') == '1')
         eng.load_state_dict(sd)
         x = torch.from_numpy(g["x"]).cuda()
         cond = torch.from_numpy(g["cond"]).cuda()
