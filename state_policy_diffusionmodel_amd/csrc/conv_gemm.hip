@@ -27,6 +27,8 @@
 //     bias / GELU / residual for Linear layers; rows on registers, channels on lanes -> each store
 //     instruction writes two full 128-byte lines.
 //   * blockIdx is remapped so that the n-tiles of one m-tile run on the same XCD (shared L2).
+#include <algorithm>
+
 #include "device_utils.h"
 
 namespace spdm {
@@ -51,7 +53,7 @@ constexpr int LDK = 36;   // padded LDS row length (floats)
 enum { PREC_F32 = 0, PREC_SPLIT = 1 };
 
 template <bool HALO, int PREC, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
     constexpr int APASS = HALO ? (M_T + 18 + 31) / 32 : M_T / 32;   // halo <= 9 rows each side (W <= 8)
     constexpr int WPASS = N_T / 32;
@@ -325,12 +327,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
     }
 
     // ---- epilogue ----
-    const int row_base = m0 + wm * MT * 32 + 4 * kh;     // + mt*32 + (r&3) + 8*(r>>2)
-    const int col_base = n0 + wn * NT * 32 + li;         // + nt*32
+    // The accumulator layout has channels on lanes and rows on registers, i.e. one dword per lane per
+    // store.  Going through LDS (the A/W slabs are dead now) turns the tile into whole rows so that
+    // every lane stores 16 bytes and a wave instruction writes two 512-byte row pieces: 4x fewer
+    // store instructions (the store tail is issue-bound, not bandwidth-bound).
+    float* srow = smem;                                  // [M_T / unit][WN][2] GroupNorm partials
+    float* otile = smem + 1024;                          // [M_T][N_T] fp32 output tile
+    const bool unit4 = (HW & 3) == 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col_l = wn * NT * 32 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row_l = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                otile[row_l * N_T + col_l] = acc[0][mt][nt][r];
+            }
+        }
 
     if (a.epi == EPI_STATS) {
-        float* srow = Abuf;                              // [M_T / unit][WN][2], aliases the A slabs
-        const bool unit4 = (HW & 3) == 0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -371,7 +387,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
                     }
                 }
             }
-        __syncthreads();
+    }
+    __syncthreads();
+
+    if (a.epi == EPI_STATS) {
         const int t_lo = m0, t_hi = min(m0 + M_T, M);
         if (t_hi > t_lo) {
             const int b_first = t_lo / HW, b_last = (t_hi - 1) / HW;
@@ -393,24 +412,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a, const 
         }
     }
 
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = col_base + nt * 32;
-            float bias = 0.f;
-            if (a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID) bias = a.bias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < M) {
-                    float v = acc[0][mt][nt][r] + bias;
-                    if (a.epi == EPI_BIAS_GELU) v = gelu_erf(v);
-                    if (a.epi == EPI_BIAS_RESID) v += a.resid[(size_t)row * a.resid_ld + col];
-                    a.dst[(size_t)row * a.dst_ld + col] = v;
+    {
+        constexpr int TPR = N_T / 4, RPP = 256 / TPR;    // threads per row, rows per pass
+        const int c4o = tid % TPR, r0 = tid / TPR;
+        const bool has_bias = (a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID);
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + c4o * 4);
+#pragma unroll 4
+        for (int p = 0; p < M_T / RPP; ++p) {
+            const int row_l = p * RPP + r0;
+            const int row = m0 + row_l;
+            if (row < M) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(otile + row_l * N_T + c4o * 4);
+                v += bias4;
+                if (a.epi == EPI_BIAS_GELU) {
+                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                 }
+                if (a.epi == EPI_BIAS_RESID)
+                    v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.resid_ld + n0 + c4o * 4);
+                *reinterpret_cast<f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4o * 4) = v;
             }
         }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -432,7 +455,8 @@ static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s
     const int halo = HALO ? a.W + 1 : 0;
     const int QA = M_T + 2 * halo;
     const int NSP = (QA + 4) & ~3;
-    const size_t lds = (size_t)(2 * (QA + 1) * LDK + 2 * N_T * LDK + 2 * NSP) * sizeof(float);
+    size_t lds = (size_t)(2 * (QA + 1) * LDK + 2 * N_T * LDK + 2 * NSP) * sizeof(float);
+    lds = std::max(lds, (size_t)(1024 + M_T * N_T) * sizeof(float));     // epilogue staging: srow + output tile
     auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT>;
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -451,7 +475,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     // shape contract of the kernel -- checked on the host so that a bad plan can never fault the GPU
     if (a.M <= 0 || a.K <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (a.K % CK != 0 || a.N % 64 != 0) return hipErrorInvalidValue;
-    if (a.src_ld % 4 != 0 || a.src_ld < a.K) return hipErrorInvalidValue;
+    if (a.src_ld % 4 != 0 || a.src_ld < a.K || a.dst_ld % 4 != 0) return hipErrorInvalidValue;
+    if (a.epi == EPI_BIAS_RESID && a.resid_ld % 4 != 0) return hipErrorInvalidValue;
     if (!(a.taps == 1 || a.taps == 3 || a.taps == 9)) return hipErrorInvalidValue;
     if (a.taps != 1 && (a.W < 1 || a.W > 8 || a.H < 1 || a.HW != a.H * a.W || a.M % a.HW != 0)) return hipErrorInvalidValue;
     if (a.taps == 3 && a.W != 1) return hipErrorInvalidValue;

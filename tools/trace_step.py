@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Print the per-launch timeline of the LAST denoise step in a rocprofv3 kernel_trace.csv."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "advance_kernel" in r["Kernel_Name"]]
+step = rows[idx[-1]:]
+end = next((i for i, r in enumerate(step) if "out_step" in r["Kernel_Name"]), len(step) - 1)
+step = step[: end + 1]
+tot = 0.0
+agg = {}
+for r in step:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot += d
+    n = r["Kernel_Name"].replace("spdm::", "").replace("void ", "").split("(")[0][:46]
+    agg[n] = agg.get(n, 0.0) + d
+    if "-v" in sys.argv:
+        print(f"{n:48s} grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):7d} vgpr={r['VGPR_Count']:>4s}+{r['Accum_VGPR_Count']:>3s} {d:9.1f} us")
+print(f"sum of kernels {tot/1e3:.2f} ms, wall {(int(step[-1]['End_Timestamp'])-int(step[0]['Start_Timestamp']))/1e6:.2f} ms")
+for n, d in sorted(agg.items(), key=lambda kv: -kv[1]):
+    print(f"  {n:48s} {d/1e3:8.3f} ms {100*d/tot:5.1f}%")
