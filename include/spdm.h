@@ -176,6 +176,13 @@ size_t spdm_device_bytes(const spdm_handle* h);
 int  spdm_profile_enable(spdm_handle* h, int32_t on);
 int  spdm_profile_read(spdm_handle* h, int64_t* launches, double* total_ms, double* total_flops);
 
+/* Micro-benchmark of ONE implicit-GEMM launch shape on synthetic data (tools/bench_gemm.py; kernel tuning
+ * only, not on the product path): conv taps in {1,3,9} over (B, H*W, Cin) -> (B, H*W, Cout).  pro: 0 none,
+ * 1 GroupNorm, 2 GroupNorm+GELU; epi: 0 GN stats, 1 bias, 2 bias+GELU, 3 bias+residual; debug: ablation bits. */
+int  spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t taps,
+                     int32_t pro, int32_t epi, int32_t split, int32_t iters, int32_t debug,
+                     double* ms_out /* [2]: ms per launch, max |out - exact-fp32 out| (debug == 0) */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
-// conv_gemm.hip -- the dominant kernel: 3x3 convolution / Linear as an implicit GEMM on the
-// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 157 TFLOP/s chip peak).
+// conv_gemm.hip -- the dominant kernel: 3x3 convolution / Linear as an implicit GEMM on the gfx950
+// matrix cores.
 //
 // Replaces, on the reference's path: every nn.Conv2d(k=3, padding=1, bias=False) of
 // DoubleConvolution (models/Unet_FiLmLayer.py:101-103) together with the GroupNorm(1,C) -> GELU
@@ -9,23 +9,24 @@
 //
 //   out[m][n] = sum_tap sum_ci  f(in[m + shift(tap)][ci]) * w[tap][n][ci]          m = b*HW + h*W + w
 //
-// Tiling (one workgroup = 4 wave64, one 128 x N_T output tile, N_T = 64 or 128):
+// Structure (one workgroup = WM x WN wave64, one (WM*MT*32) x (WN*NT*32) output tile):
 //   * K is walked in chunks of 32 input channels.  Per chunk the workgroup stages ONE halo'd slab
-//     of the input -- rows [m0-(W+1), m0+128+(W+1)) x 32 channels -- into LDS, applying f (GroupNorm
+//     of the input -- rows [m0-(W+1), m0+M_T+(W+1)) x 32 channels -- into LDS, applying f (GroupNorm
 //     affine from the producer's fp64 partial sums, optional erf-GELU) once; the 9 taps are 9
 //     shifted views of that slab, so the input is read from L2/HBM once per chunk, not 9 times.
-//     Out-of-image taps (zero padding, sample boundaries) are masked per lane at fragment read.
-//   * per (chunk, tap) the 128 x 32 weight slab w[tap][n0..][k0..] is staged to LDS.
-//   * both slabs are double-buffered through registers: global loads for the next slab are issued
-//     before the MFMA block of the current one and written to LDS after it; one barrier per tap.
-//   * LDS rows are padded 32 -> 36 floats: a half-wave's 32 lanes then read 32 distinct rows with
-//     ds_read_b128 conflict-free (row stride 144 B = 9 x 16 B, 9 odd).
-//   * each lane fetches 4 consecutive k of its row (one ds_read_b128) and feeds them to 4 MFMAs;
-//     lane half h supplies k = 8g + 4h + s in step s, identically for A and B, so the reduction
-//     order is a fixed permutation of k.
-//   * epilogue: GroupNorm partial sums (fp32 per 4-row unit -> fp64 per sample, fixed order) or
-//     bias / GELU / residual for Linear layers; rows on registers, channels on lanes -> each store
-//     instruction writes two full 128-byte lines.
+//     Out-of-image taps (zero padding, sample boundaries) read a dedicated all-zero LDS row.
+//   * weight slabs w[tap][n0..][k0..] are staged TPI taps at a time and double-buffered through
+//     registers: global loads for the next group are issued before the MFMA block of the current
+//     one and written to LDS after it; ONE workgroup barrier per group of TPI taps.  The main
+//     configuration (8 waves, 256 x 128 tile, TPI = 3) runs 72 MFMAs per wave between barriers --
+//     the measured cost of a barrier + staging round is ~600-800 cycles, so per-barrier MFMA work
+//     is what sets matrix-pipe utilisation (PMC: 35 % at 24 MFMAs per barrier).
+//   * LDS rows are padded 128 -> 144 bytes: a half-wave's 32 lanes then read 32 distinct rows with
+//     ds_read_b128 conflict-free (row stride 9 x 16 B, 9 odd).
+//   * fragment reads are software-pipelined one K=16 step ahead of the MFMAs that consume them.
+//   * epilogue: the tile goes through LDS (the slabs are dead by then) so that every lane stores
+//     16 bytes and a wave writes whole 512-byte row pieces; GroupNorm partial sums (fp32 per row
+//     unit -> fp64 per sample, fixed order) or bias / GELU / residual for Linear layers.
 //   * blockIdx is remapped so that the n-tiles of one m-tile run on the same XCD (shared L2).
 #include <algorithm>
 
@@ -35,28 +36,52 @@ namespace spdm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // PREC_F32   : operands stay fp32, v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain).
-// PREC_SPLIT : every fp32 operand x is split on the fly into two fp16 numbers
-//                  hi = fp16(x),   lo = fp16((x - hi) * 2^11)            (x = hi + lo * 2^-11 to ~2^-22 |x|)
-//              and a product a*b is evaluated as  ah*bh  +  2^-11 (ah*bl + al*bh)  with three
-//              v_mfma_f32_32x32x16_f16 (fp16 x fp16 products are exact in fp32; accumulation is fp32).
-//              The dropped al*bl term is 2^-22 relative, i.e. 4 fp32 ulps per product, random sign.
+// PREC_SPLIT : every fp32 operand x is split into two fp16 numbers  hi = fp16(x'), lo = fp16(x' - hi)
+//              of the pre-scaled value x' = x * 2^s (activations s = 4, weights s = 7; powers of two, so
+//              the scaling is exact and only moves the numbers into fp16's normal range: lo stays a
+//              normal fp16 for |x| >= 2^-7 resp. 2^-10, hi overflows only for |x| > 4094 resp. 511).
+//              A product a*b is evaluated as  ah*bh + ah*bl + al*bh  with three v_mfma_f32_32x32x16_f16
+//              into ONE fp32 accumulator (fp16 x fp16 products are exact in fp32), and the accumulator is
+//              multiplied by 2^-11 once in the epilogue.  The dropped al*bl term is 2^-22 relative (4 fp32
+//              ulps per product, random sign); measured end-to-end error is BELOW the fp32-MFMA path's,
+//              because the fp16 pipe rounds once per 16 products instead of once per product.
 //              The fp16 matrix pipe runs 16x the fp32 one per clock, so 3 MFMAs per K=16 are 5.3x the
-//              fp32-MFMA rate.  The scaling keeps lo in fp16's normal range for |x| down to ~1e-5 * 2^-11.
-//              Weights are split once at load time (host); activations at LDS-staging time.
+//              fp32-MFMA rate.  Weights are split once at load time (host); activations at LDS-staging.
+constexpr float SPLIT_ACT_SCALE = 16.0f;      // 2^4
+constexpr float SPLIT_WGT_SCALE = 128.0f;     // 2^7   (host side: spdm_api.hip upload_split)
+constexpr float SPLIT_DESCALE = 1.0f / 2048.0f;
+
+// {packed fp16 hi(a,b), packed fp16 lo(a,b)} of the pre-scaled pair, as raw bits in two floats.
+// (Written per PAIR on purpose: bit-casting a 4 x fp16 vector to 2 x u32 is miscompiled by hipcc 7.2 --
+// elements 2,3 are replaced by 0,1.)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 split_pair(float a, float b) {
+    const float xa = a * SPLIT_ACT_SCALE, xb = b * SPLIT_ACT_SCALE;
+    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
+    const f16x2 h = {ha, hb};
+    const f16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    return f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
+}
 
 constexpr int CK = 32;    // channels per K chunk
 constexpr int LDK = 36;   // padded LDS row length (floats)
 enum { PREC_F32 = 0, PREC_SPLIT = 1 };
 
-template <bool HALO, int PREC, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int RP = NTHR / 8;                                     // slab rows staged per pass
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
-    constexpr int APASS = HALO ? (M_T + 18 + 31) / 32 : M_T / 32;   // halo <= 9 rows each side (W <= 8)
-    constexpr int WPASS = N_T / 32;
+    constexpr int APASS = HALO ? (M_T + 18 + RP - 1) / RP : M_T / RP;   // halo <= 9 rows each side (W <= 8)
+    constexpr int WPASS = N_T / RP;                                  // per tap
+    constexpr int NBA = (TPI == 1) ? 2 : 1;                          // A slab buffers
+    static_assert(N_T % RP == 0 && M_T % RP == 0, "tile / thread-count mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
     const int HW = a.HW, W = a.W, H = a.H, M = a.M, K = a.K, N = a.N, taps = a.taps;
     const int halo = HALO ? (W + 1) : 0;
     const int QA = M_T + 2 * halo;
+    const int QZ = QA + 1;                    // + one all-zero row: what a masked (out-of-image) tap reads
     const int NSP = (QA + 4) & ~3;
 
     // ---- tile of this workgroup (XCD-aware, bijective remap) ----
@@ -74,23 +100,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
     const int mtile = logical / n_ntiles, ntile = logical - mtile * n_ntiles;
     const int m0 = mtile * M_T, n0 = ntile * N_T;
 
-    const int QZ = QA + 1;                    // + one all-zero row: what a masked (out-of-image) tap reads
-    float* Abuf = smem;                       // [2][QZ][LDK]
-    float* Wbuf = Abuf + 2 * QZ * LDK;        // [2][N_T][LDK]
-    float* smean = Wbuf + 2 * N_T * LDK;      // [NSP]
-    float* srstd = smean + NSP;               // [NSP]
+    float* Abuf = smem;                                   // [NBA][QZ][LDK]
+    float* Wbuf = Abuf + NBA * QZ * LDK;                  // [2][TPI][N_T][LDK]
+    float* smean = Wbuf + 2 * TPI * N_T * LDK;            // [NSP]
+    float* srstd = smean + NSP;                           // [NSP]
 
-    if (tid < 2 * LDK) Abuf[(tid / LDK) * QZ * LDK + QA * LDK + tid % LDK] = 0.f;
+    if (tid < NBA * LDK) Abuf[(tid / LDK) * QZ * LDK + QA * LDK + tid % LDK] = 0.f;
 
     // ---- prologue statistics of the samples this slab touches ----
     const bool pro = (a.pro != PRO_NONE);
-    const bool pro_gelu = (a.pro == PRO_GN_GELU);
+    const int dbg = a.debug;
+    const bool pro_gelu = (a.pro == PRO_GN_GELU) && !(dbg & DBG_NO_GELU);
     int bh_first = 0;
     if (pro) {
         const int lo = max(m0 - halo, 0), hi = min(m0 + M_T + halo, M) - 1;
         bh_first = lo / HW;
         const int bh_last = hi / HW;
-        for (int t = tid; t <= bh_last - bh_first; t += 256) {
+        for (int t = tid; t <= bh_last - bh_first; t += NTHR) {
             float mean, rstd;
             sample_mean_rstd(a.pro_stats, bh_first + t, mean, rstd);
             smean[t] = mean;
@@ -99,14 +125,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
         __syncthreads();
     }
 
-    // ---- per-thread staging assignment: 8 threads x float4 cover one 32-channel row ----
+    // ---- per-thread staging assignment: 8 threads x 16 bytes cover one 32-channel row ----
     const int srow_t = tid >> 3, c4 = tid & 7;
     bool aval[APASS];
     const float* aptr[APASS];
     float amean[APASS], arstd[APASS];
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
-        const int q = p * 32 + srow_t;
+        const int q = p * RP + srow_t;
         const int m = m0 - halo + q;
         const bool v = (q < QA) && (m >= 0) && (m < M);
         aval[p] = v;
@@ -119,11 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
             arstd[p] = srstd[b - bh_first];
         }
     }
-    const float* wptr = a.wgt + (size_t)(n0 + srow_t) * K + c4 * 4;   // + (tap*N + p*32)*K + chunk*32
+    const float* wptr = a.wgt + (size_t)(n0 + srow_t) * K + c4 * 4;   // + (tap*N + p*RP)*K + chunk*32
 
     // ---- per-lane fragment rows and tap masks ----
-    // A lane reads row (r + halo + shift(tap)) of the slab, or the all-zero row when the tap falls
-    // outside the image / the sample for its output position.
     int aoff[MT], boff[NT];
     unsigned amask[MT];
     const int koff = kh * 4;    // floats: 16 B per lane half in both slab formats
@@ -151,22 +175,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) boff[nt] = (wn * NT * 32 + nt * 32 + li) * LDK + koff;
 
-    constexpr int NACC = (PREC == PREC_SPLIT) ? 2 : 1;     // [1]: the 2^-11-scaled cross terms
-    f32x16 acc[NACC][MT][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int c = 0; c < NACC; ++c)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][mt][nt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     // Staging registers.  Everything below is written with compile-time indices and UNCONDITIONAL
     // loads (rows outside the tensor are clamped to a valid address and zeroed at LDS-write time):
     // a predicated load makes hipcc wait for it right where it is issued, and HIP's float4 struct
     // arrays end up in scratch -- both defeat the overlap of the loads with the MFMA block.
-    f32x4 areg[APASS], wreg[WPASS];
+    f32x4 areg[APASS], wreg[TPI * WPASS];
     f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};   // GroupNorm gain / offset of this thread's 4 channels
 
 #define SPDM_LOAD_A(chunk_)                                                                         \
@@ -178,161 +199,193 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
             b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (chunk_) * CK + c4 * 4);             \
         }                                                                                           \
     }
-#define SPDM_LOAD_W(chunk_, tap_)                                                                   \
+#define SPDM_LOAD_W(chunk_, tg_)                                                                    \
     {                                                                                               \
-        const float* wb_ = wptr + (size_t)(tap_) * N * K + (chunk_) * CK;                           \
-        _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                       \
-            wreg[p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * 32 * K);                  \
+        _Pragma("unroll") for (int tp_ = 0; tp_ < TPI; ++tp_) {                                    \
+            const float* wb_ = wptr + (size_t)((tg_) * TPI + tp_) * N * K + (chunk_) * CK;          \
+            _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                   \
+                wreg[tp_ * WPASS + p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * RP * K); \
+        }                                                                                           \
     }
 #define SPDM_STORE_W(buf_)                                                                          \
     {                                                                                               \
-        float* wd_ = Wbuf + (buf_) * N_T * LDK + srow_t * LDK + c4 * 4;                             \
-        _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                       \
-            *reinterpret_cast<f32x4*>(wd_ + p_ * 32 * LDK) = wreg[p_];                              \
+        float* wd_ = Wbuf + (buf_) * TPI * N_T * LDK + srow_t * LDK + c4 * 4;                       \
+        _Pragma("unroll") for (int tp_ = 0; tp_ < TPI; ++tp_)                                      \
+            _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                   \
+                *reinterpret_cast<f32x4*>(wd_ + (tp_ * N_T + p_ * RP) * LDK) = wreg[tp_ * WPASS + p_]; \
     }
     // fp32 slab row: 32 floats.  split slab row: [32 x fp16 hi | 32 x fp16 lo] (same 128 bytes).
-#define SPDM_STORE_A(chunk_, buf_)                                                                  \
+    // TRANSFORM turns the raw loaded values into what the slab holds (in the same registers; the split
+    // form packs {hi0..3} into .xy and {lo0..3} into .zw); WRITE_A puts them into LDS.
+#define SPDM_TRANSFORM_A()                                                                          \
     {                                                                                               \
-        const f32x4 g4_ = g4r, b4_ = b4r;                                                           \
-        float* ad_ = Abuf + (buf_) * QZ * LDK;                                                      \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                     \
             f32x4 v_ = areg[p_];                                                                    \
             if (pro) {                                                                              \
                 const float rs_ = arstd[p_], mu_ = amean[p_];                                       \
-                v_.x = (v_.x - mu_) * (rs_ * g4_.x) + b4_.x;                                        \
-                v_.y = (v_.y - mu_) * (rs_ * g4_.y) + b4_.y;                                        \
-                v_.z = (v_.z - mu_) * (rs_ * g4_.z) + b4_.z;                                        \
-                v_.w = (v_.w - mu_) * (rs_ * g4_.w) + b4_.w;                                        \
+                v_.x = (v_.x - mu_) * (rs_ * g4r.x) + b4r.x;                                        \
+                v_.y = (v_.y - mu_) * (rs_ * g4r.y) + b4r.y;                                        \
+                v_.z = (v_.z - mu_) * (rs_ * g4r.z) + b4r.z;                                        \
+                v_.w = (v_.w - mu_) * (rs_ * g4r.w) + b4r.w;                                        \
                 if (pro_gelu) {                                                                     \
                     v_.x = gelu_erf(v_.x); v_.y = gelu_erf(v_.y);                                   \
                     v_.z = gelu_erf(v_.z); v_.w = gelu_erf(v_.w);                                   \
                 }                                                                                   \
             }                                                                                       \
             if (!aval[p_]) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
-            if (p_ * 32 + srow_t < QA) {                                                            \
-                float* row_ = ad_ + (p_ * 32 + srow_t) * LDK;                                       \
-                if (PREC == PREC_SPLIT) {                                                           \
-                    f16x4 hi_, lo_;                                                                 \
-                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                             \
-                        const _Float16 h_ = (_Float16)v_[e_];                                       \
-                        hi_[e_] = h_;                                                               \
-                        lo_[e_] = (_Float16)((v_[e_] - (float)h_) * 2048.0f);                       \
-                    }                                                                               \
-                    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(row_) + c4 * 4) = hi_;     \
-                    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(row_) + 32 + c4 * 4) = lo_; \
+            if (PREC == PREC_SPLIT) {                                                               \
+                const f32x2 p0_ = split_pair(v_.x, v_.y), p1_ = split_pair(v_.z, v_.w);             \
+                v_ = f32x4{p0_.x, p1_.x, p0_.y, p1_.y};                                             \
+            }                                                                                       \
+            areg[p_] = v_;                                                                          \
+        }                                                                                           \
+    }
+#define SPDM_WRITE_A(buf_)                                                                          \
+    {                                                                                               \
+        float* ad_ = Abuf + (buf_) * QZ * LDK;                                                      \
+        _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                     \
+            if (p_ * RP + srow_t < QA) {                                                            \
+                float* row_ = ad_ + (p_ * RP + srow_t) * LDK;                                       \
+                if (PREC == PREC_SPLIT) {   /* hi: 8 bytes at c4*8, lo: 8 bytes at 64 + c4*8 */     \
+                    *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{areg[p_].x, areg[p_].y};       \
+                    *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{areg[p_].z, areg[p_].w};  \
                 } else {                                                                            \
-                    *reinterpret_cast<f32x4*>(row_ + c4 * 4) = v_;                                  \
+                    *reinterpret_cast<f32x4*>(row_ + c4 * 4) = areg[p_];                            \
                 }                                                                                   \
             }                                                                                       \
         }                                                                                           \
     }
 
     const int nchunks = K / CK;
-    const int niter = nchunks * taps;
+    const int ngroups = taps / TPI;
+    const int niter = nchunks * ngroups;
 
     SPDM_LOAD_A(0)
     SPDM_LOAD_W(0, 0)
-    SPDM_STORE_A(0, 0)
+    SPDM_TRANSFORM_A()
+    SPDM_WRITE_A(0)
     SPDM_STORE_W(0)
     __syncthreads();
 
-    int chunk = 0, tap = 0;
+    int chunk = 0, tg = 0;
     for (int it = 0; it < niter; ++it) {
-        // next (chunk, tap)
-        int ntap = tap + 1, nchunk = chunk;
-        if (ntap == taps) { ntap = 0; nchunk = chunk + 1; }
+        int ntg = tg + 1, nchunk = chunk;
+        if (ntg == ngroups) { ntg = 0; nchunk = chunk + 1; }
         const bool have_next = (it + 1 < niter);
-        const bool next_A = have_next && (ntap == 0);
+        const bool next_A = have_next && (ntg == 0);
         // A before W: hipcc guards the re-use of the A staging registers with a vmcnt wait that would
         // otherwise also wait for the W loads issued just before it
-        if (next_A) SPDM_LOAD_A(nchunk)
-        if (have_next) SPDM_LOAD_W(nchunk, ntap)
+        if (next_A && !(dbg & DBG_NO_ALOAD)) SPDM_LOAD_A(nchunk)
+        if (have_next && !(dbg & DBG_NO_WLOAD)) SPDM_LOAD_W(nchunk, ntg)
 
-        // ---- MFMA block on Abuf[chunk&1], Wbuf[it&1] ----
-        const float* Ab = Abuf + (chunk & 1) * QZ * LDK;
-        const float* Wb = Wbuf + (it & 1) * N_T * LDK;
-        int shift = 0;
-        if (HALO) {
-            const int dh = (taps == 9) ? tap / 3 - 1 : tap - 1;
-            const int dw = (taps == 9) ? tap % 3 - 1 : 0;
-            shift = (dh * W + dw) * LDK;
+        // ---- MFMA block: TPI taps on the A slab of this chunk and W group buffer it&1 ----
+        const float* Ab = Abuf + (NBA == 2 ? (chunk & 1) : 0) * QZ * LDK;
+        const float* Wb = Wbuf + (it & 1) * TPI * N_T * LDK;
+        const float* ap[TPI][MT];
+#pragma unroll
+        for (int tp = 0; tp < TPI; ++tp) {
+            const int tap = tg * TPI + tp;
+            int shift = 0;
+            if (HALO) {
+                const int dh = (taps == 9) ? tap / 3 - 1 : tap - 1;
+                const int dw = (taps == 9) ? tap % 3 - 1 : 0;
+                shift = (dh * W + dw) * LDK;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ap[tp][mt] = Ab + (((amask[mt] >> tap) & 1u) ? aoff[mt] + shift : zoff);
         }
-        const float* ap[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ap[mt] = Ab + (((amask[mt] >> tap) & 1u) ? aoff[mt] + shift : zoff);
 
-        if (PREC == PREC_SPLIT) {
-            // row = [hi: 32 fp16 | lo: 32 fp16]; K=16 step s, lane half kh: 8 fp16 at byte 32 s + 16 kh
+        if (dbg & DBG_NO_MFMA) {
+        } else if (PREC == PREC_SPLIT) {
+            // row = [hi: 32 fp16 | lo: 32 fp16]; K=16 step s2 of tap tp, lane half kh: 8 fp16 at byte 32 s2 + 16 kh.
+            // Two fragment sets: the reads of step st are in flight while the MFMAs of step st-1 run.
+            constexpr int NSTEP = 2 * TPI;
+            f16x8 fa[2][MT][2], fb[2][NT][2];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+            for (int st = 0; st <= NSTEP; ++st) {
+                if (st < NSTEP) {
+                    const int tp = st >> 1, s2 = st & 1, set = st & 1;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    ah[mt] = *reinterpret_cast<const f16x8*>(ap[mt] + s2 * 8);
-                    al[mt] = *reinterpret_cast<const f16x8*>(ap[mt] + 16 + s2 * 8);
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    bh[nt] = *reinterpret_cast<const f16x8*>(Wb + boff[nt] + s2 * 8);
-                    bl[nt] = *reinterpret_cast<const f16x8*>(Wb + boff[nt] + 16 + s2 * 8);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt) {
+                        fa[set][mt][0] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + s2 * 8);
+                        fa[set][mt][1] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + 16 + s2 * 8);
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[0][mt][nt], 0, 0, 0);
-                        acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[NACC - 1][mt][nt], 0, 0, 0);
-                        acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[NACC - 1][mt][nt], 0, 0, 0);
+                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + s2 * 8);
+                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + 16 + s2 * 8);
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st > 0) {
+                    const int set = (st - 1) & 1;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][0], fb[set][nt][0], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][0], fb[set][nt][1], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][1], fb[set][nt][0], acc[mt][nt], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 av[MT], bv[NT];
+            for (int tp = 0; tp < TPI; ++tp)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + g * 8);
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 av[MT], bv[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(Wb + boff[nt] + g * 8);
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(ap[tp][mt] + g * 8);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int nt = 0; nt < NT; ++nt)
+                        bv[nt] = *reinterpret_cast<const f32x4*>(Wb + tp * N_T * LDK + boff[nt] + g * 8);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[0][mt][nt], 0, 0, 0);
-                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[0][mt][nt], 0, 0, 0);
-                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[0][mt][nt], 0, 0, 0);
-                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[0][mt][nt], 0, 0, 0);
-                    }
-            }
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+                        }
+                }
         }
 
         if (have_next) SPDM_STORE_W((it + 1) & 1)
-        if (next_A) SPDM_STORE_A(nchunk, nchunk & 1)
+        if (next_A) {
+            SPDM_TRANSFORM_A()
+            if (NBA == 1) __syncthreads();      // every wave is done reading the single A slab
+            SPDM_WRITE_A(NBA == 2 ? (nchunk & 1) : 0)
+        }
         __syncthreads();
-        tap = ntap;
+        tg = ntg;
         chunk = nchunk;
     }
 #undef SPDM_LOAD_A
 #undef SPDM_LOAD_W
-#undef SPDM_STORE_A
 #undef SPDM_STORE_W
+#undef SPDM_TRANSFORM_A
+#undef SPDM_WRITE_A
 
-    if (PREC == PREC_SPLIT) {   // fold the scaled cross terms in: x = hi*hi + 2^-11 (hi*lo + lo*hi)
+    if (PREC == PREC_SPLIT) {   // undo the operand pre-scaling (exact: power of two)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[0][mt][nt][r] = acc[0][mt][nt][r] + acc[NACC - 1][mt][nt][r] * (1.0f / 2048.0f);
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= SPLIT_DESCALE;
     }
 
     // ---- epilogue ----
     // The accumulator layout has channels on lanes and rows on registers, i.e. one dword per lane per
     // store.  Going through LDS (the A/W slabs are dead now) turns the tile into whole rows so that
-    // every lane stores 16 bytes and a wave instruction writes two 512-byte row pieces: 4x fewer
+    // every lane stores 16 bytes and a wave instruction writes whole 512-byte row pieces: 4x fewer
     // store instructions (the store tail is issue-bound, not bandwidth-bound).
     float* srow = smem;                                  // [M_T / unit][WN][2] GroupNorm partials
-    float* otile = smem + 1024;                          // [M_T][N_T] fp32 output tile
+    constexpr int SROW_FLOATS = M_T * WN * 2;
+    float* otile = smem + SROW_FLOATS;                   // [M_T][N_T] fp32 output tile
     const bool unit4 = (HW & 3) == 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -342,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row_l = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                otile[row_l * N_T + col_l] = acc[0][mt][nt][r];
+                otile[row_l * N_T + col_l] = acc[mt][nt][r];
             }
         }
 
@@ -358,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float v = acc[0][mt][nt][4 * g + j];
+                            const float v = acc[mt][nt][4 * g + j];
                             s1 += v;
                             s2 += v * v;
                         }
@@ -374,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const float v = acc[0][mt][nt][4 * g + j];
+                            const float v = acc[mt][nt][4 * g + j];
                             s1 += v;
                             s2 += v * v;
                         }
@@ -395,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
         if (t_hi > t_lo) {
             const int b_first = t_lo / HW, b_last = (t_hi - 1) / HW;
             const int ush = unit4 ? 2 : 0;
-            for (int t = tid; t <= b_last - b_first; t += 256) {
+            for (int t = tid; t <= b_last - b_first; t += NTHR) {
                 const int b = b_first + t;
                 const int r_lo = max(b * HW, t_lo) - m0, r_hi = min((b + 1) * HW, t_hi) - m0;
                 double s1 = 0.0, s2 = 0.0;
@@ -413,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
     }
 
     {
-        constexpr int TPR = N_T / 4, RPP = 256 / TPR;    // threads per row, rows per pass
+        constexpr int TPR = N_T / 4, RPP = NTHR / TPR;    // threads per row, rows per pass
         const int c4o = tid % TPR, r0 = tid / TPR;
         const bool has_bias = (a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID);
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -422,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
         for (int p = 0; p < M_T / RPP; ++p) {
             const int row_l = p * RPP + r0;
             const int row = m0 + row_l;
-            if (row < M) {
+            if (row < M && !(dbg & DBG_NO_STORE)) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(otile + row_l * N_T + c4o * 4);
                 v += bias4;
                 if (a.epi == EPI_BIAS_GELU) {
@@ -437,37 +490,42 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmArgs a, con
 }
 
 // -------------------------------------------------------------------------------------------------
-GemmGeom gemm_geometry(int M, int N, int HW) {
+// Launch configurations.  cfg 0: 4 waves, 128 x {64,128}, one tap per barrier (exact-fp32 path and
+// 1-tap GEMMs).  cfg 1: 8 waves, 256 x {64,128}, three taps per barrier (split path, 3x3 / 3x1 convs).
+static bool use_big_tile(int M, int taps, int split) { return split && taps != 1 && M >= 256; }
+
+GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
     GemmGeom g;
-    g.m_tile = 128;
+    g.m_tile = use_big_tile(M, taps, split) ? 256 : 128;
     g.n_tile = (N % 128 == 0) ? 128 : 64;
     g.n_tiles = N / g.n_tile;
     g.slots = stats_slots(HW, g.m_tile, g.n_tiles);
-    (void)M;
     return g;
 }
 
 double gemm_flops(const GemmArgs& a) { return 2.0 * (double)a.M * (double)a.N * (double)a.K * (double)a.taps; }
 
-template <bool HALO, int PREC, int WM, int WN, int MT, int NT>
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI>
 static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
-    constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
+    constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32, NTHR = WM * WN * 64;
+    constexpr int NBA = (TPI == 1) ? 2 : 1;
     const int halo = HALO ? a.W + 1 : 0;
     const int QA = M_T + 2 * halo;
     const int NSP = (QA + 4) & ~3;
-    size_t lds = (size_t)(2 * (QA + 1) * LDK + 2 * N_T * LDK + 2 * NSP) * sizeof(float);
-    lds = std::max(lds, (size_t)(1024 + M_T * N_T) * sizeof(float));     // epilogue staging: srow + output tile
-    auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT>;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
+    size_t lds = (size_t)(NBA * (QA + 1) * LDK + 2 * TPI * N_T * LDK + 2 * NSP) * sizeof(float);
+    lds = std::max(lds, (size_t)(M_T * WN * 2 + M_T * N_T) * sizeof(float));     // epilogue staging: srow + output tile
+    if (lds > 160 * 1024 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
+    auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
-        lds_set = 160 * 1024;
+        attr_set = true;
     }
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     const int grid = n_mtiles * g.n_tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, g.slots);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, g.slots);
     return hipGetLastError();
 }
 
@@ -486,21 +544,25 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.epi == EPI_STATS && a.epi_stats == nullptr) return hipErrorInvalidValue;
     if ((a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID) && a.bias == nullptr) return hipErrorInvalidValue;
     if (a.epi == EPI_BIAS_RESID && a.resid == nullptr) return hipErrorInvalidValue;
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW);
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split);
     if (a.split) {
         if (a.taps == 1) {
-            if (g.n_tile == 128) return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 2>(a, g, s);
-            return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 1>(a, g, s);
+            if (g.n_tile == 128) return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 2, 1>(a, g, s);
+            return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 1, 1>(a, g, s);
         }
-        if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2>(a, g, s);
-        return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1>(a, g, s);
+        if (g.m_tile == 256) {
+            if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3>(a, g, s);
+            return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3>(a, g, s);
+        }
+        if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2, 1>(a, g, s);
+        return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 1>(a, g, s);
     }
     if (a.taps == 1) {
-        if (g.n_tile == 128) return launch_cfg<false, PREC_F32, 2, 2, 2, 2>(a, g, s);
-        return launch_cfg<false, PREC_F32, 2, 2, 2, 1>(a, g, s);
+        if (g.n_tile == 128) return launch_cfg<false, PREC_F32, 2, 2, 2, 2, 1>(a, g, s);
+        return launch_cfg<false, PREC_F32, 2, 2, 2, 1, 1>(a, g, s);
     }
-    if (g.n_tile == 128) return launch_cfg<true, PREC_F32, 2, 2, 2, 2>(a, g, s);
-    return launch_cfg<true, PREC_F32, 2, 2, 2, 1>(a, g, s);
+    if (g.n_tile == 128) return launch_cfg<true, PREC_F32, 2, 2, 2, 2, 1>(a, g, s);
+    return launch_cfg<true, PREC_F32, 2, 2, 2, 1, 1>(a, g, s);
 }
 
 }  // namespace spdm

@@ -43,11 +43,13 @@ struct GemmArgs {
     int H, W, HW;                      // spatial dims of this level
     int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
     int epi;  double* epi_stats;   const float* bias;  const float* resid;  int resid_ld;
+    int debug;                         // ablation knobs for spdm_bench_gemm only (0 in the product path)
 };
+enum { DBG_NO_MFMA = 1, DBG_NO_WLOAD = 2, DBG_NO_GELU = 4, DBG_NO_STORE = 8, DBG_NO_ALOAD = 16 };
 
 // geometry of the stats the GEMM writes (EPI_STATS)
 struct GemmGeom { int m_tile, n_tile, n_tiles, slots; };
-GemmGeom gemm_geometry(int M, int N, int HW);
+GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split);
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 

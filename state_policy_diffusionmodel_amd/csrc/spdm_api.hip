@@ -357,17 +357,18 @@ struct Loader {
         if (d != e->ndim || numel != e->numel || e->offset + e->numel > n) { err = fail(SPDM_ERR_INVALID, "tensor '%s': bad extent", name.c_str()); return nullptr; }
         return blob + e->offset;
     }
-    // fp32 [rows][K] -> per 32-k chunk [32 x fp16 hi | 32 x fp16 lo], lo = fp16((x - hi) * 2^11); same byte size
+    // fp32 [rows][K] -> per 32-k chunk [32 x fp16 hi | 32 x fp16 lo] of x' = 128 x (conv_gemm.hip, PREC_SPLIT):
+    // hi = fp16(x'), lo = fp16(x' - hi); same byte size as the fp32 array
     float* upload_split(const std::vector<float>& v, size_t K) {
         if (K % 32 != 0) { err = fail(SPDM_ERR_INVALID, "split weights need K %% 32 == 0"); return nullptr; }
         std::vector<float> out(v.size());
         for (size_t base = 0; base < v.size(); base += 32) {
             _Float16* hp = reinterpret_cast<_Float16*>(&out[base]);
             for (int j = 0; j < 32; ++j) {
-                const float x = v[base + j];
+                const float x = v[base + j] * 128.0f;
                 const _Float16 hi = (_Float16)x;
                 hp[j] = hi;
-                hp[32 + j] = (_Float16)((x - (float)hi) * 2048.0f);
+                hp[32 + j] = (_Float16)(x - (float)hi);
             }
         }
         return upload(out);
@@ -618,14 +619,16 @@ struct Ctx {
     Value conv(const Value& in, const ConvW& w, int level, bool gelu, const float* gamma, const float* beta) {
         Value out;
         const int HW = HWl(level), M = B * HW;
-        const GemmGeom g = gemm_geometry(M, w.cout, HW);
+        const int split = (h->split && w.cin % 32 == 0) ? 1 : 0;   // decided by shape only: the dry run has no weights yet
+        const GemmGeom g = gemm_geometry(M, w.cout, HW, w.taps, split);
         out.t = talloc(w.cout, level);
         out.st = salloc(HW, w.cout, g.m_tile, g.n_tiles);
         out.gamma = gamma; out.beta = beta;
         if (err || dry) return out;
         GemmArgs a{};
-        a.split = (h->split && w.ws) ? 1 : 0;
+        a.split = split;
         a.src = in.t.p; a.src_ld = in.t.C; a.wgt = a.split ? w.ws : w.w; a.dst = out.t.p; a.dst_ld = w.cout;
+        if (a.wgt == nullptr) { if (!err) err = fail(SPDM_ERR_STATE, "plan: conv weights missing"); return out; }
         a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
         a.H = Hl(level); a.W = Wl(level); a.HW = HW;
         a.pro = in.pending_gn() ? (gelu ? PRO_GN_GELU : PRO_GN) : PRO_NONE;
@@ -996,5 +999,98 @@ extern "C" int spdm_profile_read(spdm_handle* h, int64_t* launches, double* tota
     if (launches) *launches = h->prof_launches;
     if (total_ms) *total_ms = h->prof_ms;
     if (total_flops) *total_flops = h->prof_flops;
+    return SPDM_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Micro-benchmark of one implicit-GEMM launch shape on synthetic data (tools/bench_gemm.py); not on
+// the product path.  Returns the average device time per launch in *ms_out (HIP events).
+extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t taps,
+                               int32_t pro, int32_t epi, int32_t split, int32_t iters, int32_t debug, double* ms_out) {
+    if (!ms_out || iters < 1) return fail(SPDM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const int HW = H * W, M = B * HW;
+    const GemmGeom g = gemm_geometry(M, Cout, HW, taps, split);
+    float *src = nullptr, *wgt = nullptr, *wgt32 = nullptr, *dst = nullptr, *dst2 = nullptr, *gb = nullptr, *resid = nullptr;
+    double *st_in = nullptr, *st_out = nullptr;
+    const size_t nsrc = (size_t)M * Cin, nw = (size_t)taps * Cout * Cin, ndst = (size_t)M * Cout;
+    HIP_TRY(hipMalloc((void**)&src, nsrc * 4));
+    HIP_TRY(hipMalloc((void**)&wgt, nw * 4));
+    HIP_TRY(hipMalloc((void**)&wgt32, nw * 4));
+    HIP_TRY(hipMalloc((void**)&dst2, ndst * 4));
+    HIP_TRY(hipMalloc((void**)&dst, ndst * 4));
+    HIP_TRY(hipMalloc((void**)&resid, ndst * 4));
+    HIP_TRY(hipMalloc((void**)&gb, (size_t)(Cin + Cout) * 2 * 4));
+    HIP_TRY(hipMalloc((void**)&st_in, (size_t)B * 2 * 8));
+    HIP_TRY(hipMalloc((void**)&st_out, (size_t)B * g.slots * 2 * 8));
+    {   // deterministic pseudo-random fill (values ~U(-1,1)); split weights are packed as at load time
+        std::vector<float> hsrc(nsrc), hw(nw), hgb((size_t)(Cin + Cout) * 2);
+        unsigned x = 12345u;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((x >> 8) * (1.0f / 8388608.0f)) - 1.0f; };
+        for (auto& v : hsrc) v = rnd();
+        for (auto& v : hw) v = rnd() * 0.05f;
+        for (auto& v : hgb) v = 1.0f + 0.1f * rnd();
+        HIP_TRY(hipMemcpy(wgt32, hw.data(), nw * 4, hipMemcpyHostToDevice));
+        if (split) {
+            std::vector<float> out(nw);
+            for (size_t base = 0; base < nw; base += 32) {
+                _Float16* hp = reinterpret_cast<_Float16*>(&out[base]);
+                for (int j = 0; j < 32; ++j) {
+                    const float v = hw[base + j] * 128.0f;
+                    const _Float16 hi = (_Float16)v;
+                    hp[j] = hi;
+                    hp[32 + j] = (_Float16)(v - (float)hi);
+                }
+            }
+            hw.swap(out);
+        }
+        std::vector<double> hst((size_t)B * 2);
+        for (int b = 0; b < B; ++b) { hst[2 * b] = 0.0; hst[2 * b + 1] = (double)Cin * HW / 3.0; }
+        HIP_TRY(hipMemcpy(src, hsrc.data(), nsrc * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(wgt, hw.data(), nw * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(gb, hgb.data(), hgb.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(st_in, hst.data(), hst.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(resid, 0, ndst * 4));
+    }
+    GemmArgs a{};
+    a.src = src; a.src_ld = Cin; a.wgt = wgt; a.split = split; a.dst = dst; a.dst_ld = Cout;
+    a.M = M; a.K = Cin; a.N = Cout; a.taps = taps; a.H = H; a.W = W; a.HW = HW;
+    a.pro = pro;
+    a.pro_stats.p = st_in; a.pro_stats.slots = 1; a.pro_stats.m_tile = HW; a.pro_stats.n_tiles = 1; a.pro_stats.HW = HW;
+    a.pro_stats.inv_count = 1.0 / ((double)Cin * HW);
+    a.pro_gamma = gb; a.pro_beta = gb + Cin;
+    a.epi = epi; a.epi_stats = st_out; a.bias = gb + 2 * Cin; a.resid = resid; a.resid_ld = Cout;
+    a.debug = debug;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipError_t e = launch_gemm(a, nullptr);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_gemm(a, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_gemm(a, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    double maxdiff = -1.0;
+    if (e == hipSuccess && debug == 0) {      // self-check: same data through the exact fp32-MFMA configuration
+        GemmArgs b2 = a;
+        b2.split = 0; b2.wgt = wgt32; b2.dst = dst2;
+        e = launch_gemm(b2, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        std::vector<float> h1(ndst), h2(ndst);
+        if (e == hipSuccess) e = hipMemcpy(h1.data(), dst, ndst * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(h2.data(), dst2, ndst * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            maxdiff = 0.0;
+            for (size_t i = 0; i < ndst; ++i) maxdiff = std::max(maxdiff, (double)std::fabs(h1[i] - h2[i]));
+        }
+    }
+    ms_out[1] = maxdiff;
+    (void)hipFree(wgt32); (void)hipFree(dst2);
+    (void)hipFree(src); (void)hipFree(wgt); (void)hipFree(dst); (void)hipFree(resid); (void)hipFree(gb); (void)hipFree(st_in); (void)hipFree(st_out);
+    if (e != hipSuccess) return fail(SPDM_ERR_HIP, "bench_gemm: %s", hipGetErrorString(e));
+    *ms_out = ms / iters;
     return SPDM_OK;
 }
