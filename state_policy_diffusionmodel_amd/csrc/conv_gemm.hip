@@ -81,6 +81,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     constexpr int APASS = HALO ? (M_T + 18 + RP - 1) / RP : M_T / RP;   // halo <= 9 rows each side (W <= 8)
     constexpr int WPASS = N_T / RP;                                  // per tap
     constexpr int NBA = (TPI == 1) ? 2 : 1;                          // A slab buffers
+    constexpr bool PP = (NTHR == 512);                               // ping-pong schedule (see main loop)
+    static_assert(!PP || NBA == 1, "ping-pong uses the single-slab hand-over");
     static_assert(N_T % RP == 0 && M_T % RP == 0, "tile / thread-count mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -104,6 +106,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     float* Wbuf = Abuf + NBA * QZ * LDK;                  // [2][TPI][N_T][LDK]
     float* smean = Wbuf + 2 * TPI * N_T * LDK;            // [NSP]
     float* srstd = smean + NSP;                           // [NSP]
+
+    // diagnostic stamps (DBG_STAMP): thread 0 of each half of the workgroup that owns logical tile 37
+#ifdef SPDM_DIAG
+    const bool stamping = (a.debug & DBG_STAMP) && a.stamps != nullptr && logical == 37 && (tid & 255) == 0;
+    int nstamp = 0;
+#endif
+#ifdef SPDM_DIAG
+#define SPDM_STAMP()                                                                                 \
+    if (stamping && nstamp < 126) a.stamps[(tid >> 8) * 128 + nstamp++] = (unsigned long long)clock64();
+#else
+#define SPDM_STAMP()
+#endif
+    SPDM_STAMP()
 
     if (tid < NBA * LDK) Abuf[(tid / LDK) * QZ * LDK + QA * LDK + tid % LDK] = 0.f;
 
@@ -264,105 +279,143 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     SPDM_LOAD_W(0, 0)
     SPDM_TRANSFORM_A()
     SPDM_WRITE_A(0)
+    SPDM_STAMP()
     SPDM_STORE_W(0)
     __syncthreads();
+    SPDM_STAMP()
+
+    // The MFMA block of one iteration (TPI taps on the A slab of `chunk_` and W group buffer `wbuf_`).
+#define SPDM_MFMA_BLOCK(chunk_, tg_, wbuf_)                                                         \
+    {                                                                                               \
+        const float* Ab = Abuf + (NBA == 2 ? ((chunk_) & 1) : 0) * QZ * LDK;                        \
+        const float* Wb = Wbuf + (wbuf_) * TPI * N_T * LDK;                                         \
+        const float* ap[TPI][MT];                                                                   \
+        _Pragma("unroll") for (int tp = 0; tp < TPI; ++tp) {                                       \
+            const int tap = (tg_) * TPI + tp;                                                       \
+            int shift = 0;                                                                          \
+            if (HALO) {                                                                             \
+                const int dh = (taps == 9) ? tap / 3 - 1 : tap - 1;                                 \
+                const int dw = (taps == 9) ? tap % 3 - 1 : 0;                                       \
+                shift = (dh * W + dw) * LDK;                                                        \
+            }                                                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+                ap[tp][mt] = Ab + (((amask[mt] >> tap) & 1u) ? aoff[mt] + shift : zoff);            \
+        }                                                                                           \
+        if (dbg & DBG_NO_MFMA) {                                                                    \
+        } else if (PREC == PREC_SPLIT) {                                                            \
+            /* row = [hi: 32 fp16 | lo: 32 fp16]; K=16 step s2 of tap tp, lane half kh: 8 fp16 at  \
+               byte 32 s2 + 16 kh.  Two fragment sets: the reads of step st are in flight while    \
+               the MFMAs of step st-1 run. */                                                       \
+            constexpr int NSTEP = 2 * TPI;                                                          \
+            f16x8 fa[2][MT][2], fb[2][NT][2];                                                       \
+            _Pragma("unroll") for (int st = 0; st <= NSTEP; ++st) {                                \
+                if (st < NSTEP) {                                                                   \
+                    const int tp = st >> 1, s2 = st & 1, set = st & 1;                              \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                            \
+                        fa[set][mt][0] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + s2 * 8);      \
+                        fa[set][mt][1] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + 16 + s2 * 8); \
+                    }                                                                               \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                            \
+                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + s2 * 8);      \
+                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + 16 + s2 * 8); \
+                    }                                                                               \
+                }                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                if (st > 0) {                                                                       \
+                    const int set = (st - 1) & 1;                                                   \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                        \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][0], fb[set][nt][0], acc[mt][nt], 0, 0, 0); \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][0], fb[set][nt][1], acc[mt][nt], 0, 0, 0); \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][1], fb[set][nt][0], acc[mt][nt], 0, 0, 0); \
+                        }                                                                           \
+                }                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+            }                                                                                       \
+        } else {                                                                                    \
+            _Pragma("unroll") for (int tp = 0; tp < TPI; ++tp)                                     \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                    \
+                    f32x4 av[MT], bv[NT];                                                           \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
+                        av[mt] = *reinterpret_cast<const f32x4*>(ap[tp][mt] + g * 8);               \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                              \
+                        bv[nt] = *reinterpret_cast<const f32x4*>(Wb + tp * N_T * LDK + boff[nt] + g * 8); \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                        \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0); \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0); \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0); \
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0); \
+                        }                                                                           \
+                }                                                                                   \
+        }                                                                                           \
+    }
 
     int chunk = 0, tg = 0;
-    for (int it = 0; it < niter; ++it) {
-        int ntg = tg + 1, nchunk = chunk;
-        if (ntg == ngroups) { ntg = 0; nchunk = chunk + 1; }
-        const bool have_next = (it + 1 < niter);
-        const bool next_A = have_next && (ntg == 0);
-        // A before W: hipcc guards the re-use of the A staging registers with a vmcnt wait that would
-        // otherwise also wait for the W loads issued just before it
-        if (next_A && !(dbg & DBG_NO_ALOAD)) SPDM_LOAD_A(nchunk)
-        if (have_next && !(dbg & DBG_NO_WLOAD)) SPDM_LOAD_W(nchunk, ntg)
-
-        // ---- MFMA block: TPI taps on the A slab of this chunk and W group buffer it&1 ----
-        const float* Ab = Abuf + (NBA == 2 ? (chunk & 1) : 0) * QZ * LDK;
-        const float* Wb = Wbuf + (it & 1) * TPI * N_T * LDK;
-        const float* ap[TPI][MT];
-#pragma unroll
-        for (int tp = 0; tp < TPI; ++tp) {
-            const int tap = tg * TPI + tp;
-            int shift = 0;
-            if (HALO) {
-                const int dh = (taps == 9) ? tap / 3 - 1 : tap - 1;
-                const int dw = (taps == 9) ? tap % 3 - 1 : 0;
-                shift = (dh * W + dw) * LDK;
+#ifdef SPDM_DIAG
+    constexpr bool PP_COMPILED = PP;
+#else
+    constexpr bool PP_COMPILED = false;      // product build: no second loop body, no extra register pressure
+#endif
+    if (PP_COMPILED && (dbg & DBG_PP)) {
+        // Ping-pong schedule (measured SLOWER than the plain schedule on MI355X; kept for experiments:
+        // enable with DBG_PP) (8 waves): waves 0-3 (one per SIMD) and waves 4-7 alternate between
+        // "run the MFMA block" and "stage the next slabs" (LDS writes of W, GroupNorm/GELU/split
+        // transform of A), separated by workgroup barriers -- the matrix pipe always has exactly one
+        // MFMA-issuing wave per SIMD and the staging work of one half hides behind the MFMAs of the other.
+        const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
+        for (int it = 0; it < niter; ++it) {
+            int ntg = tg + 1, nchunk = chunk;
+            if (ntg == ngroups) { ntg = 0; nchunk = chunk + 1; }
+            const bool have_next = (it + 1 < niter);
+            const bool next_A = have_next && (ntg == 0);
+            if (next_A && !(dbg & DBG_NO_ALOAD)) SPDM_LOAD_A(nchunk)
+            if (have_next && !(dbg & DBG_NO_WLOAD)) SPDM_LOAD_W(nchunk, ntg)
+            for (int ph = 0; ph < 2; ++ph) {
+                SPDM_STAMP()
+                if (grp == ph) {
+                    SPDM_MFMA_BLOCK(chunk, tg, it & 1)
+                } else {
+                    if (have_next) SPDM_STORE_W((it + 1) & 1)
+                    if (next_A) SPDM_TRANSFORM_A()
+                }
+                SPDM_STAMP()
+                __syncthreads();
             }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ap[tp][mt] = Ab + (((amask[mt] >> tap) & 1u) ? aoff[mt] + shift : zoff);
-        }
-
-        if (dbg & DBG_NO_MFMA) {
-        } else if (PREC == PREC_SPLIT) {
-            // row = [hi: 32 fp16 | lo: 32 fp16]; K=16 step s2 of tap tp, lane half kh: 8 fp16 at byte 32 s2 + 16 kh.
-            // Two fragment sets: the reads of step st are in flight while the MFMAs of step st-1 run.
-            constexpr int NSTEP = 2 * TPI;
-            f16x8 fa[2][MT][2], fb[2][NT][2];
-#pragma unroll
-            for (int st = 0; st <= NSTEP; ++st) {
-                if (st < NSTEP) {
-                    const int tp = st >> 1, s2 = st & 1, set = st & 1;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        fa[set][mt][0] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + s2 * 8);
-                        fa[set][mt][1] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + 16 + s2 * 8);
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + s2 * 8);
-                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + 16 + s2 * 8);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (st > 0) {
-                    const int set = (st - 1) & 1;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][0], fb[set][nt][0], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][0], fb[set][nt][1], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][1], fb[set][nt][0], acc[mt][nt], 0, 0, 0);
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            if (next_A) {               // both halves are done with the single A slab
+                SPDM_WRITE_A(0)
+                __syncthreads();
             }
-        } else {
-#pragma unroll
-            for (int tp = 0; tp < TPI; ++tp)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 av[MT], bv[NT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(ap[tp][mt] + g * 8);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        bv[nt] = *reinterpret_cast<const f32x4*>(Wb + tp * N_T * LDK + boff[nt] + g * 8);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
-                        }
-                }
+            tg = ntg;
+            chunk = nchunk;
         }
-
-        if (have_next) SPDM_STORE_W((it + 1) & 1)
-        if (next_A) {
-            SPDM_TRANSFORM_A()
-            if (NBA == 1) __syncthreads();      // every wave is done reading the single A slab
-            SPDM_WRITE_A(NBA == 2 ? (nchunk & 1) : 0)
+    } else {
+        for (int it = 0; it < niter; ++it) {
+            int ntg = tg + 1, nchunk = chunk;
+            if (ntg == ngroups) { ntg = 0; nchunk = chunk + 1; }
+            const bool have_next = (it + 1 < niter);
+            const bool next_A = have_next && (ntg == 0);
+            // A before W: hipcc guards the re-use of the A staging registers with a vmcnt wait that would
+            // otherwise also wait for the W loads issued just before it
+            if (next_A && !(dbg & DBG_NO_ALOAD)) SPDM_LOAD_A(nchunk)
+            if (have_next && !(dbg & DBG_NO_WLOAD)) SPDM_LOAD_W(nchunk, ntg)
+            SPDM_STAMP()
+            SPDM_MFMA_BLOCK(chunk, tg, it & 1)
+            SPDM_STAMP()
+            if (have_next) SPDM_STORE_W((it + 1) & 1)
+            if (next_A) {
+                SPDM_TRANSFORM_A()
+                if (NBA == 1) __syncthreads();      // every wave is done reading the single A slab
+                SPDM_WRITE_A(NBA == 2 ? (nchunk & 1) : 0)
+            }
+            SPDM_STAMP()
+            __syncthreads();
+            SPDM_STAMP()
+            tg = ntg;
+            chunk = nchunk;
         }
-        __syncthreads();
-        tg = ntg;
-        chunk = nchunk;
     }
+#undef SPDM_MFMA_BLOCK
 #undef SPDM_LOAD_A
 #undef SPDM_LOAD_W
 #undef SPDM_STORE_W
@@ -383,6 +436,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     // store.  Going through LDS (the A/W slabs are dead now) turns the tile into whole rows so that
     // every lane stores 16 bytes and a wave instruction writes whole 512-byte row pieces: 4x fewer
     // store instructions (the store tail is issue-bound, not bandwidth-bound).
+    SPDM_STAMP()
     float* srow = smem;                                  // [M_T / unit][WN][2] GroupNorm partials
     constexpr int SROW_FLOATS = M_T * WN * 2;
     float* otile = smem + SROW_FLOATS;                   // [M_T][N_T] fp32 output tile
@@ -441,7 +495,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                 }
             }
     }
+    SPDM_STAMP()
     __syncthreads();
+    SPDM_STAMP()
 
     if (a.epi == EPI_STATS) {
         const int t_lo = m0, t_hi = min(m0 + M_T, M);
@@ -487,6 +543,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             }
         }
     }
+    SPDM_STAMP()
+#ifdef SPDM_DIAG
+    if (stamping) a.stamps[(tid >> 8) * 128 + 127] = (unsigned long long)nstamp;
+#endif
+#undef SPDM_STAMP
 }
 
 // -------------------------------------------------------------------------------------------------

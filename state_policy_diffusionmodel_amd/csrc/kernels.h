@@ -44,8 +44,9 @@ struct GemmArgs {
     int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
     int epi;  double* epi_stats;   const float* bias;  const float* resid;  int resid_ld;
     int debug;                         // ablation knobs for spdm_bench_gemm only (0 in the product path)
+    unsigned long long* stamps;        // DBG_STAMP: [2][128] s_memtime stamps of one workgroup (diagnostic builds of the bench)
 };
-enum { DBG_NO_MFMA = 1, DBG_NO_WLOAD = 2, DBG_NO_GELU = 4, DBG_NO_STORE = 8, DBG_NO_ALOAD = 16 };
+enum { DBG_NO_MFMA = 1, DBG_NO_WLOAD = 2, DBG_NO_GELU = 4, DBG_NO_STORE = 8, DBG_NO_ALOAD = 16, DBG_PP = 64, DBG_STAMP = 128 };
 
 // geometry of the stats the GEMM writes (EPI_STATS)
 struct GemmGeom { int m_tile, n_tile, n_tiles, slots; };

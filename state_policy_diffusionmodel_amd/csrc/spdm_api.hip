@@ -1061,6 +1061,12 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     a.pro_gamma = gb; a.pro_beta = gb + Cin;
     a.epi = epi; a.epi_stats = st_out; a.bias = gb + 2 * Cin; a.resid = resid; a.resid_ld = Cout;
     a.debug = debug;
+    unsigned long long* d_stamps = nullptr;
+    if (debug & DBG_STAMP) {
+        HIP_TRY(hipMalloc((void**)&d_stamps, 256 * 8));
+        HIP_TRY(hipMemset(d_stamps, 0, 256 * 8));
+        a.stamps = d_stamps;
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -1088,6 +1094,19 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
         }
     }
     ms_out[1] = maxdiff;
+    if (d_stamps) {      // print the stamp deltas of the traced workgroup (cycles between consecutive stamps)
+        unsigned long long hs[256];
+        if (hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int g = 0; g < 2; ++g) {
+                const int n = (int)hs[g * 128 + 127];
+                printf("stamps half %d (%d):", g, n);
+                for (int i = 1; i < n && i < 126; ++i) printf(" %llu", hs[g * 128 + i] - hs[g * 128 + i - 1]);
+                printf("  total %llu\n", n > 1 ? hs[g * 128 + n - 1] - hs[g * 128] : 0ull);
+            }
+            fflush(stdout);
+        }
+        (void)hipFree(d_stamps);
+    }
     (void)hipFree(wgt32); (void)hipFree(dst2);
     (void)hipFree(src); (void)hipFree(wgt); (void)hipFree(dst); (void)hipFree(resid); (void)hipFree(gb); (void)hipFree(st_in); (void)hipFree(st_out);
     if (e != hipSuccess) return fail(SPDM_ERR_HIP, "bench_gemm: %s", hipGetErrorString(e));
