@@ -7,6 +7,9 @@
 // the keys with an online softmax -- every lane of a wave reads the same K/V row, i.e. an LDS
 // broadcast, conflict-free.  fp32 VALU FMA runs at the same chip rate as fp32 MFMA on gfx950, and
 // the whole attention core is ~2.5 % of the step's FLOPs.
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_utils.h"
 
 namespace spdm {
@@ -96,6 +99,234 @@ hipError_t launch_attention(const float* qkv, float* out, int B, int L, int C, i
     }
 #undef SPDM_ATT
     return hipGetLastError();
+}
+
+
+// =================================================================================================
+// MFMA attention core (L >= 32): flash-style, one wave per 32 queries of one (sample, head).
+//
+//   S^T = K Q^T  per 32-key block:  A = K rows (keys), B = Q^T (queries on the MFMA's lanes)
+//         -> each lane owns ONE query column: its 16 accumulator registers are 16 of the block's 32 keys,
+//            the other 16 sit in lane^32.  Softmax over keys = register reduction + one cross-half
+//            shuffle; the running max / sum / rescale factor are per-lane scalars.
+//   O^T += V^T P^T: the P^T block is ALREADY in B-operand position (rows = keys = the summed index live
+//            in the registers, columns = queries on the lanes): registers 8s..8s+7 are the fragment of
+//            k-step s; element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3) of the block, and the
+//            V^T fragment is gathered from LDS in that same key order.  No LDS round-trip for P.
+//   All products use the split-fp16 scheme of conv_gemm.hip (x*2^s = hi + lo, hi*hi + hi*lo + lo*hi,
+//   fp32 accumulate): q,k,v pre-scaled by 16, p by 1024.
+// K (row-major, rows padded to d+8 halfs) and V^T (rows padded to Lp+4 halfs) of the head are staged in LDS
+// as fp16 hi/lo once per workgroup; both paddings make the fragment reads bank-conflict-free.
+typedef float f32x16a __attribute__((ext_vector_type(16)));
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef float f32x2a __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8a __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4a __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2a __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+// exp(x) for x <= 0 through v_exp_f32 with a compensated argument (keeps ~1e-7 relative error up to |x| ~ 80)
+__device__ __forceinline__ float exp_neg(float x) {
+    const float t = x * 1.44269504f;
+    const float tl = __fmaf_rn(x, 1.44269504f, -t) + x * 1.925963033e-8f;
+    return __builtin_amdgcn_exp2f(t) * (1.0f + tl * 0.69314718f);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                             int L, int C, int heads, int qblocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    constexpr int KS = D / 16;             // k-steps of the S product
+    constexpr int MO = (D + 31) / 32;      // 32-row tiles of O^T
+    constexpr int KROW = D + 8;            // halfs per K row
+    const int Lp = (L + 31) & ~31;
+    const int VROW = Lp + 4;               // halfs per V^T row
+    _Float16* Khi = reinterpret_cast<_Float16*>(smraw);
+    _Float16* Klo = Khi + (size_t)Lp * KROW;
+    _Float16* Vhi = Klo + (size_t)Lp * KROW;
+    _Float16* Vlo = Vhi + (size_t)32 * MO * VROW;
+
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    int bid = blockIdx.x;
+    const int qb = bid % qblocks; bid /= qblocks;
+    const int hd = bid % heads;
+    const int b = bid / heads;
+    const size_t ld = (size_t)3 * C;
+    const float* base = qkv + (size_t)b * L * ld + hd * D;
+
+    // ---- stage K and V^T of this (sample, head) as split fp16 ----
+    constexpr int D4 = D / 4;
+    for (int i = tid; i < Lp * D4; i += nthr) {
+        const int j = i / D4, c = i - j * D4;
+        f32x4a kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (j < L) {
+            kv = *reinterpret_cast<const f32x4a*>(base + j * ld + C + c * 4);
+            vv = *reinterpret_cast<const f32x4a*>(base + j * ld + 2 * C + c * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 h, l2;
+            split1(kv[e] * 16.0f, h, l2);
+            Khi[j * KROW + c * 4 + e] = h;
+            Klo[j * KROW + c * 4 + e] = l2;
+            split1(vv[e] * 16.0f, h, l2);
+            Vhi[(c * 4 + e) * VROW + j] = h;
+            Vlo[(c * 4 + e) * VROW + j] = l2;
+        }
+    }
+    if (D < 32 * MO) {      // zero the padding rows of V^T (d = 16: rows 16..31)
+        for (int i = tid; i < (32 * MO - D) * Lp; i += nthr) {
+            const int r = D + i / Lp, j = i % Lp;
+            Vhi[r * VROW + j] = (_Float16)0.f;
+            Vlo[r * VROW + j] = (_Float16)0.f;
+        }
+    }
+    __syncthreads();
+
+    const int q0 = qb * 128 + wave * 32;
+    if (q0 >= L) return;                                   // (whole wave) nothing to do
+    const int q = q0 + li;
+    const int qc = min(q, L - 1);
+
+    // ---- Q fragments (B operand): Q[q][16 ks + 8 kh + j], pre-multiplied by 1/sqrt(d) like torch does ----
+    const float scale = 1.0f / sqrtf((float)D);
+    f16x8a qh[KS], ql[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float* qp = base + (size_t)qc * ld + 16 * ks + 8 * kh;
+        const f32x4a a0 = *reinterpret_cast<const f32x4a*>(qp), a1 = *reinterpret_cast<const f32x4a*>(qp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 h, l2;
+            split1((a0[e] * scale) * 16.0f, h, l2);
+            qh[ks][e] = h; ql[ks][e] = l2;
+            split1((a1[e] * scale) * 16.0f, h, l2);
+            qh[ks][4 + e] = h; ql[ks][4 + e] = l2;
+        }
+    }
+
+    f32x16a acc_o[MO];
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[mo][r] = 0.f;
+    float m = -1e30f, lsum = 0.f;
+
+    for (int kb = 0; kb < Lp / 32; ++kb) {
+        // S^T block = K_blk Q^T
+        f32x16a acc_s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8a k_h = *reinterpret_cast<const f16x8a*>(Khi + (kb * 32 + li) * KROW + 16 * ks + 8 * kh);
+            const f16x8a k_l = *reinterpret_cast<const f16x8a*>(Klo + (kb * 32 + li) * KROW + 16 * ks + 8 * kh);
+            acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_h, qh[ks], acc_s, 0, 0, 0);
+            acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_h, ql[ks], acc_s, 0, 0, 0);
+            acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_l, qh[ks], acc_s, 0, 0, 0);
+        }
+        // online softmax over the block's 32 keys of this lane's query
+        float sc[16];
+        float mloc = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            sc[r] = (key < L) ? acc_s[r] * (1.0f / 256.0f) : -1e30f;
+            mloc = fmaxf(mloc, sc[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m, mloc);
+        const float alpha = exp_neg(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = exp_neg(sc[r] - m_new);
+            psum += sc[r];
+        }
+        lsum = lsum * alpha + psum;
+        m = m_new;
+        // P^T fragments straight from the registers (k-step s = registers 8s .. 8s+7)
+        f16x8a p_h[2], p_l[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l2;
+                split1(sc[8 * s2 + j] * 1024.0f, h, l2);
+                p_h[s2][j] = h;
+                p_l[s2][j] = l2;
+            }
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[mo][r] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                // V^T[row mo*32 + li][keys kb*32 + 16 s2 + 4 kh + {0..3}, + 8 + {0..3}]
+                const _Float16* vr_h = Vhi + (mo * 32 + li) * VROW + kb * 32 + 16 * s2 + 4 * kh;
+                const _Float16* vr_l = Vlo + (mo * 32 + li) * VROW + kb * 32 + 16 * s2 + 4 * kh;
+                const f16x4a vh0 = *reinterpret_cast<const f16x4a*>(vr_h), vh1 = *reinterpret_cast<const f16x4a*>(vr_h + 8);
+                const f16x4a vl0 = *reinterpret_cast<const f16x4a*>(vr_l), vl1 = *reinterpret_cast<const f16x4a*>(vr_l + 8);
+                const f16x8a v_h = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+                const f16x8a v_l = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+                acc_o[mo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_h[s2], acc_o[mo], 0, 0, 0);
+                acc_o[mo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_l[s2], acc_o[mo], 0, 0, 0);
+                acc_o[mo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h[s2], acc_o[mo], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / (lsum * 16384.0f);          // p scale 1024 x v scale 16
+    if (q < L) {
+        float* orow = out + ((size_t)b * L + q) * C + hd * D;
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int drow = mo * 32 + 8 * g + 4 * kh;     // d index of registers 4g .. 4g+3
+                if (drow < D) {
+                    const f32x4a v = {acc_o[mo][4 * g] * inv, acc_o[mo][4 * g + 1] * inv, acc_o[mo][4 * g + 2] * inv,
+                                      acc_o[mo][4 * g + 3] * inv};
+                    *reinterpret_cast<f32x4a*>(orow + drow) = v;
+                }
+            }
+    }
+}
+
+template <int D>
+static hipError_t launch_attention_mfma(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s) {
+    const int Lp = (L + 31) & ~31;
+    constexpr int MO = (D + 31) / 32;
+    const size_t lds = ((size_t)2 * Lp * (D + 8) + (size_t)2 * 32 * MO * (Lp + 4)) * sizeof(_Float16);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = attention_mfma_kernel<D>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+    }
+    const int qblocks = (L + 127) / 128;
+    const int waves = std::min(4, (L + 31) / 32);
+    hipLaunchKernelGGL(kern, dim3(B * heads * qblocks), dim3(64 * waves), lds, s, qkv, out, L, C, heads, qblocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s) {
+    if (B <= 0 || L <= 0 || heads <= 0 || C % heads != 0 || C % 4 != 0) return hipErrorInvalidValue;
+    const int d = C / heads;
+    if (L >= 32 && getenv("SPDM_ATTN_VALU") == nullptr) {
+        switch (d) {
+            case 16: return launch_attention_mfma<16>(qkv, out, B, L, C, heads, s);
+            case 32: return launch_attention_mfma<32>(qkv, out, B, L, C, heads, s);
+            case 64: return launch_attention_mfma<64>(qkv, out, B, L, C, heads, s);
+            default: break;
+        }
+    }
+    return launch_attention(qkv, out, B, L, C, heads, s);
 }
 
 }  // namespace spdm

@@ -540,6 +540,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                 if (a.epi == EPI_BIAS_RESID)
                     v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.resid_ld + n0 + c4o * 4);
                 *reinterpret_cast<f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4o * 4) = v;
+                if (a.row_stats != nullptr) {   // LayerNorm partials of the consumer: the row sits on TPR consecutive lanes
+                    float s1 = (v.x + v.y) + (v.z + v.w);
+                    float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+                    for (int o2 = TPR >> 1; o2 > 0; o2 >>= 1) {
+                        s1 += __shfl_xor(s1, o2, 64);
+                        s2 += __shfl_xor(s2, o2, 64);
+                    }
+                    if (c4o == 0) {
+                        double* rs = a.row_stats + ((size_t)row * n_ntiles + ntile) * 2;
+                        rs[0] = (double)s1;
+                        rs[1] = (double)s2;
+                    }
+                }
             }
         }
     }

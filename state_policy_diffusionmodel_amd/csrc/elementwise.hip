@@ -217,7 +217,7 @@ hipError_t launch_upcat(const AffineSrc& up, const AffineSrc& skip, float* dst, 
 __global__ __launch_bounds__(256) void film_apply_kernel(const AffineSrc src, const float* __restrict__ temb,
                                                          const int* __restrict__ t_dev, int t_count,
                                                          const float* __restrict__ film, float* __restrict__ dst,
-                                                         int HW, int rows_per_block) {
+                                                         double* __restrict__ row_stats, int HW, int rows_per_block) {
     __shared__ float sm[2];
     const int b = blockIdx.x, tid = threadIdx.x;
     float mean, rstd;
@@ -243,21 +243,35 @@ __global__ __launch_bounds__(256) void film_apply_kernel(const AffineSrc src, co
             v.x = fs.x * v.x + fb.x; v.y = fs.y * v.y + fb.y; v.z = fs.z * v.z + fb.z; v.w = fs.w * v.w + fb.w;
         }
         *reinterpret_cast<float4*>(dst + o) = v;
+        if (row_stats != nullptr) {      // a token row lives on C4 consecutive lanes of one wave (C4 in {16,32,64})
+            float s1 = (v.x + v.y) + (v.z + v.w);
+            float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            for (int o2 = C4 >> 1; o2 > 0; o2 >>= 1) {
+                s1 += __shfl_xor(s1, o2, 64);
+                s2 += __shfl_xor(s2, o2, 64);
+            }
+            if (c4 == 0) {
+                double* rs = row_stats + ((size_t)b * HW + r) * 2;
+                rs[0] = (double)s1;
+                rs[1] = (double)s2;
+            }
+        }
     }
 }
 
 hipError_t launch_film_apply(const AffineSrc& src, const float* temb_table, const int* t_dev, int t_count,
-                             const float* film, float* dst, int B, int HW, hipStream_t s) {
+                             const float* film, float* dst, double* row_stats, int B, int HW, hipStream_t s) {
     const int C4 = src.C / 4;
     if (src.C % 4 != 0 || C4 > 256 || 256 % C4 != 0 || B <= 0) return hipErrorInvalidValue;
+    if (row_stats != nullptr && !(C4 == 16 || C4 == 32 || C4 == 64)) return hipErrorInvalidValue;
     const int rpb = rows_per_block_for(HW, B);
     hipLaunchKernelGGL(film_apply_kernel, dim3(B, (HW + rpb - 1) / rpb), dim3(256), 0, s, src, temb_table, t_dev,
-                       t_count, film, dst, HW, rpb);
+                       t_count, film, dst, row_stats, HW, rpb);
     return hipGetLastError();
 }
 
 hipError_t launch_gn_apply(const AffineSrc& src, float* dst, int B, int HW, hipStream_t s) {
-    return launch_film_apply(src, nullptr, nullptr, 1, nullptr, dst, B, HW, s);
+    return launch_film_apply(src, nullptr, nullptr, 1, nullptr, dst, nullptr, B, HW, s);
 }
 
 // -------------------------------------------------------------------------------------------------

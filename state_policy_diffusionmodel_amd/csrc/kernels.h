@@ -43,6 +43,7 @@ struct GemmArgs {
     int H, W, HW;                      // spatial dims of this level
     int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
     int epi;  double* epi_stats;   const float* bias;  const float* resid;  int resid_ld;
+    double* row_stats;                 // optional: per-row {sum, sum^2} of the STORED values, [row][n_tiles][2] (LayerNorm of the consumer)
     int debug;                         // ablation knobs for spdm_bench_gemm only (0 in the product path)
     unsigned long long* stamps;        // DBG_STAMP: [2][128] s_memtime stamps of one workgroup (diagnostic builds of the bench)
 };
@@ -69,9 +70,11 @@ hipError_t launch_pool(const AffineSrc& src, float* dst, int B, int H, int W, hi
 hipError_t launch_upcat(const AffineSrc& up, const AffineSrc& skip, float* dst, int B, int Hin, int Win,
                         hipStream_t s);
 // block tail: y = scale * (GN(x) + temb[t]) + bias   (FiLM; film == nullptr: y = GN(x) + temb)
+// row_stats (optional): per-token {sum, sum^2} over C of y as fp64 -- the LayerNorm statistics the
+// attention block's first GEMM applies in its load prologue
 hipError_t launch_film_apply(const AffineSrc& src, const float* temb_table /*[T][C]*/, const int* t_dev,
-                             int t_count, const float* film /*[B][2C] or null*/, float* dst, int B, int HW,
-                             hipStream_t s);
+                             int t_count, const float* film /*[B][2C] or null*/, float* dst, double* row_stats,
+                             int B, int HW, hipStream_t s);
 // plain GN apply (materialise): y = GN(x)
 hipError_t launch_gn_apply(const AffineSrc& src, float* dst, int B, int HW, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int C,
@@ -99,6 +102,7 @@ hipError_t launch_set_step(int* step_dev, int* t_dev, const int* timesteps_dev, 
 
 // ---- attention core (attention.hip): softmax(q k^T / sqrt d) v per (sample, head) -----------
 hipError_t launch_attention(const float* qkv /*[B*L][3C]*/, float* out /*[B*L][C]*/, int B, int L, int C,
-                            int heads, hipStream_t s);
+                            int heads, hipStream_t s);        // VALU kernel (small L)
+hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s);  // MFMA kernel for L >= 32
 
 }  // namespace spdm

@@ -658,35 +658,52 @@ struct Ctx {
         return out;
     }
     // y[rows][N] = x[rows][K] @ W^T + b  (+GELU | +resid)
-    void linear(const float* x, int ld, int rows, const LinW& w, float* y, int epi, const float* resid) {
+    // per-token LayerNorm statistics buffer: [rows][n_tiles][2] fp64 (StatsRef with HW = 1: "sample" = row)
+    StatsBuf row_stats_alloc(int rows, int C, int n_tiles) {
+        StatsBuf sb;
+        size_t off = 0;
+        if (!h->arena.alloc(sizeof(double) * 2 * (size_t)rows * n_tiles, &off)) {
+            if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
+            return sb;
+        }
+        sb.off = off; sb.p = (double*)(h->arena.base + off); sb.valid = true;
+        sb.ref.p = sb.p; sb.ref.slots = n_tiles; sb.ref.m_tile = 1 << 30; sb.ref.n_tiles = n_tiles; sb.ref.HW = 1;
+        sb.ref.inv_count = 1.0 / (double)C;
+        return sb;
+    }
+    void linear(const float* x, int ld, int rows, const LinW& w, float* y, int epi, const float* resid,
+                const StatsBuf* ln = nullptr, const float* ln_g = nullptr, const float* ln_b = nullptr,
+                double* row_stats_out = nullptr) {
         if (err || dry) return;
         GemmArgs a{};
         a.split = (h->split && w.ws) ? 1 : 0;
         a.src = x; a.src_ld = ld; a.wgt = a.split ? w.ws : w.w; a.dst = y; a.dst_ld = w.out;
         a.M = rows; a.K = w.in; a.N = w.out; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
         a.pro = PRO_NONE; a.epi = epi; a.bias = w.b; a.resid = resid; a.resid_ld = w.out;
+        if (ln) { a.pro = PRO_GN; a.pro_stats = ln->ref; a.pro_gamma = ln_g; a.pro_beta = ln_b; }   // LayerNorm in the load prologue
+        a.row_stats = row_stats_out;
         check(launch_gemm(a, s), "linear GEMM");
     }
-    // SelfAttention.forward, models/Unet_FiLmLayer.py:71-82.  Consumes x, returns the block output.
-    Tensor attention(Tensor& x, const AttnW& w, int level) {
+    // SelfAttention.forward, models/Unet_FiLmLayer.py:71-82.  Consumes x (and its per-token LayerNorm
+    // statistics xs, produced by film_apply), returns the block output.  Both LayerNorms run as the load
+    // prologue of the GEMM that consumes them: self.ln -> in_proj, ff_self[0] -> ff_self[1].
+    Tensor attention(Tensor& x, StatsBuf& xs, const AttnW& w, int level) {
         const int L = HWl(level), rows = B * L, C = w.C;
-        Tensor ln = ralloc(rows, C);
-        if (!err && !dry) check(launch_layernorm(x.p, w.ln_g, w.ln_b, ln.p, rows, C, s), "layernorm");
         Tensor qkv = ralloc(rows, 3 * C);
-        linear(ln.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr);
-        free(ln);
+        linear(x.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr, &xs, w.ln_g, w.ln_b);
+        free(xs);
         Tensor att = ralloc(rows, C);
-        if (!err && !dry) check(launch_attention(qkv.p, att.p, B, L, C, 4, s), "attention core");
+        if (!err && !dry) check(launch_attention_auto(qkv.p, att.p, B, L, C, 4, s), "attention core");
         free(qkv);
         Tensor av = talloc(C, level);
-        linear(att.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p);
+        const int nt_av = (C % 128 == 0) ? C / 128 : C / 64;      // n-tiles of the out_proj GEMM (gemm_geometry)
+        StatsBuf avs = row_stats_alloc(rows, C, nt_av);
+        linear(att.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p, nullptr, nullptr, nullptr, avs.p);
         free(att);
         free(x);
-        Tensor ln2 = ralloc(rows, C);
-        if (!err && !dry) check(launch_layernorm(av.p, w.ff_ln_g, w.ff_ln_b, ln2.p, rows, C, s), "layernorm");
         Tensor f1 = ralloc(rows, C);
-        linear(ln2.p, C, rows, w.ff1, f1.p, EPI_BIAS_GELU, nullptr);
-        free(ln2);
+        linear(av.p, C, rows, w.ff1, f1.p, EPI_BIAS_GELU, nullptr, &avs, w.ff_ln_g, w.ff_ln_b);
+        free(avs);
         Tensor out = talloc(C, level);
         linear(f1.p, C, rows, w.ff2, out.p, EPI_BIAS_RESID, av.p);
         free(f1);
@@ -694,11 +711,12 @@ struct Ctx {
         return out;
     }
     // tail of DownSample/UpSample.forward: + time embedding, FiLM.  Consumes v.
-    Tensor film_tail(Value& v, const ResampleW& w, int blk, int level, bool use_cond) {
+    Tensor film_tail(Value& v, const ResampleW& w, int blk, int level, bool use_cond, StatsBuf* row_stats) {
         Tensor y = talloc(w.cout, level);
+        if (row_stats) *row_stats = row_stats_alloc(B * HWl(level), w.cout, 1);
         if (!err && !dry)
             check(launch_film_apply(asrc(v), w.temb_table, h->d_t, (h_tcount), (use_cond && h->cfg.cond_dim > 0) ? h->d_film[blk] : nullptr,
-                                    y.p, B, HWl(level), s), "film_apply");
+                                    y.p, row_stats ? row_stats->p : nullptr, B, HWl(level), s), "film_apply");
         free(v);
         return y;
     }
@@ -740,9 +758,10 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         // `cur` stays alive: it is a skip connection
         Value a = c.double_conv(p, h->down[i].dc1, lout);
         Value b2 = c.double_conv(a, h->down[i].dc2, lout);
-        Tensor y = c.film_tail(b2, h->down[i], i, lout, use_cond);
+        StatsBuf ys;
+        Tensor y = c.film_tail(b2, h->down[i], i, lout, use_cond, h->cfg.attention ? &ys : nullptr);
         c.tap(dn[i], y);
-        if (h->cfg.attention) y = c.attention(y, h->sa[i], lout);
+        if (h->cfg.attention) y = c.attention(y, ys, h->sa[i], lout);
         c.tap(xn[i], y);
         Value nv;
         nv.t = y;
@@ -773,9 +792,10 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         c.free(skip);
         Value a = c.double_conv(cat, h->up[i].dc1, lout);
         Value b3 = c.double_conv(a, h->up[i].dc2, lout);
-        Tensor y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond);
+        StatsBuf ys;
+        Tensor y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond, h->cfg.attention ? &ys : nullptr);
         c.tap(un[i], y);
-        if (h->cfg.attention) y = c.attention(y, h->sa[3 + i], lout);
+        if (h->cfg.attention) y = c.attention(y, ys, h->sa[3 + i], lout);
         c.tap(an[i], y);
         Value nv;
         nv.t = y;
