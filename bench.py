@@ -177,22 +177,33 @@ def main():
 
     if rank == 0:
         value = world * B * K / el
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        peak = 157.3                                        # fp32 MFMA, MI355X_MICROARCH.md chip table
+        # Roofline of the dominant kernel class (all conv3x3 implicit-GEMM launches of the timed steps).
+        # algorithmic = 2 * MACs the launches actually evaluate (level-3 zero taps skipped), fp32-equivalent.
+        # The default path issues 3 fp16 MFMAs per fp32-equivalent product (split precision, fp32 accumulate),
+        # so the matrix pipe executes 3x the algorithmic FLOPs and is priced against the DENSE fp16 MFMA peak
+        # (1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz); the exact path is priced against the fp32 MFMA peak.
+        algo = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        split = eng.split_precision
+        achieved = algo * 3.0 if split else algo
+        peak = 2516.6 if split else 157.3
+        kernel = ("conv_gemm_kernel (3x3 implicit GEMM; split-fp16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per K=16, fp32 accumulate)"
+                  if split else "conv_gemm_kernel (3x3 implicit GEMM; v_mfma_f32_32x32x2_f32)")
         line = {
             "metric": "denoise-steps/sec (B=4096, horizon=32)",
             "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "contraction_path": "split-fp16 MFMA, fp32 accumulate" if eng.split_precision else "fp32 MFMA",
             "batch_steps_per_s": K / el,
             "config": {"workload": f"{args.kind.upper()} T={T}, {B} trajectories/GPU, horizon {H}, state_dim {D}, "
                                    f"cond {obs_h}x{obs_dim}, UNet_Film attention {'on' if attention else 'off'}, "
                                    f"inpaint_horizon 1, random-init weights, device Philox noise",
                        "global_batch": world * B, "horizon": H, "state_dim": D, "parallelism": f"batch-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (3x3 implicit GEMM, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
+                         "traffic": None, "algorithmic_fp32_equiv_tflops": algo, "fp32_mfma_peak_tflops": 157.3,
+                         "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "share_of_step_time": conv_ms / (el * 1e3)},
         }
         if world == 1 and not args.no_cpu_baseline:

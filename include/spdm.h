@@ -166,6 +166,9 @@ int  spdm_sample_result(spdm_handle* h, float* d_out, void* stream);
 int  spdm_debug_tensor(spdm_handle* h, const char* name, float* d_out, size_t cap_floats,
                        int32_t shape_out[4]);
 
+/* 1 if the handle's contractions run on the split-fp16 MFMA path, 0 on the exact fp32 MFMA path. */
+int32_t spdm_uses_split_precision(const spdm_handle* h);
+
 /* Workspace bytes currently reserved on the device (weights + arena). */
 size_t spdm_device_bytes(const spdm_handle* h);
 

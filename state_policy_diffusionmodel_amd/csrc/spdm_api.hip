@@ -333,6 +333,8 @@ extern "C" void spdm_destroy(spdm_handle* h) {
     delete h;
 }
 
+extern "C" int32_t spdm_uses_split_precision(const spdm_handle* h) { return (h && h->split) ? 1 : 0; }
+
 extern "C" size_t spdm_device_bytes(const spdm_handle* h) { return h ? h->persistent_bytes + h->arena.cap : 0; }
 
 // -------------------------------------------------------------------------------------------------

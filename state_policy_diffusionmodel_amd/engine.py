@@ -67,6 +67,11 @@ class SpdmEngine:
             pass
 
     @property
+    def split_precision(self) -> bool:
+        """True: contractions on the split-fp16 MFMA path (default); False: exact fp32 MFMA."""
+        return bool(self.lib.spdm_uses_split_precision(self._h))
+
+    @property
     def device_bytes(self) -> int:
         return int(self.lib.spdm_device_bytes(self._h))
 
