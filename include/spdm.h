@@ -186,6 +186,10 @@ int  spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, int32_t Ci
                      int32_t pro, int32_t epi, int32_t split, int32_t iters, int32_t debug,
                      double* ms_out /* [2]: ms per launch, max |out - exact-fp32 out| (debug == 0) */);
 
+/* Op-level test hook: d_y = GELU(d_x) evaluated with the device erf that the conv prologues use
+ * (nn.GELU(), models/Unet_FiLmLayer.py:104). */
+int  spdm_op_gelu(const float* d_x, float* d_y, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

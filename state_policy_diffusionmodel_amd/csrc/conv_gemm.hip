@@ -390,21 +390,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             chunk = nchunk;
         }
     } else {
+        // 8-wave workgroups stagger the A-slab transform (GroupNorm affine, erf-GELU, fp16 split -- ~30 VALU
+        // instructions per element) between their two halves: waves 0-3 load the next slab one tap group
+        // EARLIER and transform it BEFORE their last MFMA block of the chunk, waves 4-7 transform AFTER theirs,
+        // so one half's VALU work runs while the other half keeps the matrix pipe busy.
+        const bool early = (NTHR == 512) && (ngroups >= 2) && (__builtin_amdgcn_readfirstlane(tid >> 8) == 0);
         for (int it = 0; it < niter; ++it) {
             int ntg = tg + 1, nchunk = chunk;
             if (ntg == ngroups) { ntg = 0; nchunk = chunk + 1; }
             const bool have_next = (it + 1 < niter);
             const bool next_A = have_next && (ntg == 0);
+            const bool more_chunks = (chunk + 1 < nchunks);
             // A before W: hipcc guards the re-use of the A staging registers with a vmcnt wait that would
             // otherwise also wait for the W loads issued just before it
-            if (next_A && !(dbg & DBG_NO_ALOAD)) SPDM_LOAD_A(nchunk)
+            if (!(dbg & DBG_NO_ALOAD)) {
+                if (early) {
+                    if (more_chunks && tg == ngroups - 2) SPDM_LOAD_A(chunk + 1)
+                } else {
+                    if (next_A) SPDM_LOAD_A(nchunk)
+                }
+            }
             if (have_next && !(dbg & DBG_NO_WLOAD)) SPDM_LOAD_W(nchunk, ntg)
+            if (early && next_A) SPDM_TRANSFORM_A()
             SPDM_STAMP()
             SPDM_MFMA_BLOCK(chunk, tg, it & 1)
             SPDM_STAMP()
             if (have_next) SPDM_STORE_W((it + 1) & 1)
             if (next_A) {
-                SPDM_TRANSFORM_A()
+                if (!early) SPDM_TRANSFORM_A()
                 if (NBA == 1) __syncthreads();      // every wave is done reading the single A slab
                 SPDM_WRITE_A(NBA == 2 ? (nchunk & 1) : 0)
             }

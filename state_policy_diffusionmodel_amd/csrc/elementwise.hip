@@ -334,6 +334,16 @@ hipError_t launch_mish_pad(const float* cond, float* dst, int B, int cond_dim, i
     return hipGetLastError();
 }
 
+// device gelu_erf exposed for an op-level test (spdm_op_gelu)
+__global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = gelu_erf(x[i]);
+}
+hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+
 // nn.SiLU() of emb_layer (models/Unet_FiLmLayer.py:137)
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

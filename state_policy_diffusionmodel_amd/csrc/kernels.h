@@ -81,6 +81,7 @@ hipError_t launch_layernorm(const float* x, const float* g, const float* b, floa
                             hipStream_t s);
 hipError_t launch_mish_pad(const float* cond, float* dst, int B, int cond_dim, int Kp, hipStream_t s);
 hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t s);
+hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s);
 
 struct StepArgs {
     const float* feat;            // (B, Hp*Wp, 64) channels-last

@@ -1135,3 +1135,11 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     *ms_out = ms / iters;
     return SPDM_OK;
 }
+
+// op-level test hook: y = GELU(x) with the device's own erf (the one every conv prologue uses)
+extern "C" int spdm_op_gelu(const float* d_x, float* d_y, size_t n, void* stream) {
+    if (!d_x || !d_y || n == 0) return fail(SPDM_ERR_INVALID, "bad argument");
+    HIP_TRY(launch_gelu(d_x, d_y, n, (hipStream_t)stream));
+    if (!stream) HIP_TRY(hipStreamSynchronize(nullptr));
+    return SPDM_OK;
+}
