@@ -29,6 +29,7 @@
 //     unit -> fp64 per sample, fixed order) or bias / GELU / residual for Linear layers.
 //   * blockIdx is remapped so that the n-tiles of one m-tile run on the same XCD (shared L2).
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_utils.h"
 
@@ -73,7 +74,7 @@ constexpr int CK = 32;    // channels per K chunk
 constexpr int LDK = 36;   // padded LDS row length (floats)
 enum { PREC_F32 = 0, PREC_SPLIT = 1 };
 
-template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI>
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI, bool W2>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int RP = NTHR / 8;                                     // slab rows staged per pass
@@ -83,6 +84,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     constexpr int NBA = (TPI == 1) ? 2 : 1;                          // A slab buffers
     constexpr bool PP = (NTHR == 512);                               // ping-pong schedule (see main loop)
     static_assert(!PP || NBA == 1, "ping-pong uses the single-slab hand-over");
+    // W2: image width 2 (level-2 maps).  A third of the (position, tap) pairs of a 3x3 kernel then hit zero
+    // padding: for w = 0 the dw = -1 column, for w = 1 the dw = +1 column.  Each wave's 64 rows are PERMUTED so
+    // that MFMA tile 0 holds the w = 0 positions and tile 1 the w = 1 positions (row 2i + mt instead of
+    // 32 mt + i); the two side columns then fuse into ONE virtual tap per kernel row -- tile 0 multiplies
+    // w[dh][+1], tile 1 w[dh][-1] -- and a kernel row costs 2 taps of MFMAs instead of 3.  Same products,
+    // same sums: only all-zero terms are dropped.
+    static_assert(!W2 || (HALO && TPI == 3 && MT == 2 && PREC == PREC_SPLIT), "W2 needs the 3-tap split configuration");
+#define SPDM_ROW(mt_, i_) (wm * MT * 32 + (W2 ? 2 * (i_) + (mt_) : (mt_) * 32 + (i_)))
     static_assert(N_T % RP == 0 && M_T % RP == 0, "tile / thread-count mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     const int koff = kh * 4;    // floats: 16 B per lane half in both slab formats
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int r = wm * MT * 32 + mt * 32 + li;
+        const int r = SPDM_ROW(mt, li);
         aoff[mt] = (r + halo) * LDK + koff;
         unsigned mask = HALO ? 0u : 1u;
         if (HALO) {
@@ -302,6 +311,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                 ap[tp][mt] = Ab + (((amask[mt] >> tap) & 1u) ? aoff[mt] + shift : zoff);            \
         }                                                                                           \
         if (dbg & DBG_NO_MFMA) {                                                                    \
+        } else if (W2) {                                                                            \
+            /* 8 half-steps: {centre, side} x {k-step 0, 1} x {tile 0, tile 1}; reads of half-step hs  \
+               are in flight while the MFMAs of half-step hs-1 run */                                \
+            f16x8 fa[2][2], fb[2][NT][2];                                                           \
+            _Pragma("unroll") for (int hs = 0; hs <= 8; ++hs) {                                    \
+                if (hs < 8) {                                                                       \
+                    const int vt = hs >> 2, s2 = (hs >> 1) & 1, mt = hs & 1, set = hs & 1;          \
+                    const int tp = (vt == 0) ? 1 : (mt == 0 ? 2 : 0);                               \
+                    fa[set][0] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + s2 * 8);              \
+                    fa[set][1] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + 16 + s2 * 8);         \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                            \
+                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + s2 * 8);      \
+                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + 16 + s2 * 8); \
+                    }                                                                               \
+                }                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                if (hs > 0) {                                                                       \
+                    const int mt = (hs - 1) & 1, set = (hs - 1) & 1;                                \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                            \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0], fb[set][nt][0], acc[mt][nt], 0, 0, 0); \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0], fb[set][nt][1], acc[mt][nt], 0, 0, 0); \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][1], fb[set][nt][0], acc[mt][nt], 0, 0, 0); \
+                    }                                                                               \
+                }                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+            }                                                                                       \
         } else if (PREC == PREC_SPLIT) {                                                            \
             /* row = [hi: 32 fp16 | lo: 32 fp16]; K=16 step s2 of tap tp, lane half kh: 8 fp16 at  \
                byte 32 s2 + 16 kh.  Two fragment sets: the reads of step st are in flight while    \
@@ -453,7 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     float* srow = smem;                                  // [M_T / unit][WN][2] GroupNorm partials
     constexpr int SROW_FLOATS = M_T * WN * 2;
     float* otile = smem + SROW_FLOATS;                   // [M_T][N_T] fp32 output tile
-    const bool unit4 = (HW & 3) == 0;
+    const bool unit4 = !W2 && (HW & 3) == 0;      // W2: a register quad is 4 rows 2 apart -> per-row partials
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -461,7 +496,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             const int col_l = wn * NT * 32 + nt * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row_l = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int row_l = SPDM_ROW(mt, (r & 3) + 8 * (r >> 2) + 4 * kh);
                 otile[row_l * N_T + col_l] = acc[mt][nt][r];
             }
         }
@@ -471,7 +506,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int r0 = wm * MT * 32 + mt * 32 + 8 * g + 4 * kh;     // tile-local row of register 4g
+                const int r0 = wm * MT * 32 + mt * 32 + 8 * g + 4 * kh;     // tile-local row of register 4g (unpermuted)
                 if (unit4) {
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -501,8 +536,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                         s1 = half_sum(s1);
                         s2 = half_sum(s2);
                         if (li == 0) {
-                            srow[((r0 + j) * WN + wn) * 2] = s1;
-                            srow[((r0 + j) * WN + wn) * 2 + 1] = s2;
+                            const int rr = SPDM_ROW(mt, 8 * g + 4 * kh + j);
+                            srow[(rr * WN + wn) * 2] = s1;
+                            srow[(rr * WN + wn) * 2 + 1] = s2;
                         }
                     }
                 }
@@ -575,6 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     if (stamping) a.stamps[(tid >> 8) * 128 + 127] = (unsigned long long)nstamp;
 #endif
 #undef SPDM_STAMP
+#undef SPDM_ROW
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -593,7 +630,7 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
 
 double gemm_flops(const GemmArgs& a) { return 2.0 * (double)a.M * (double)a.N * (double)a.K * (double)a.taps; }
 
-template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI>
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI, bool W2 = false>
 static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32, NTHR = WM * WN * 64;
     constexpr int NBA = (TPI == 1) ? 2 : 1;
@@ -603,7 +640,7 @@ static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s
     size_t lds = (size_t)(NBA * (QA + 1) * LDK + 2 * TPI * N_T * LDK + 2 * NSP) * sizeof(float);
     lds = std::max(lds, (size_t)(M_T * WN * 2 + M_T * N_T) * sizeof(float));     // epilogue staging: srow + output tile
     if (lds > 160 * 1024 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
-    auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI>;
+    auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI, W2>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -639,6 +676,10 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
             return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 1, 1>(a, g, s);
         }
         if (g.m_tile == 256) {
+            if (a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && getenv("SPDM_NO_W2") == nullptr) {   // level-2 maps: zero-tap skipping
+                if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3, true>(a, g, s);
+                return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3, true>(a, g, s);
+            }
             if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3>(a, g, s);
             return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3>(a, g, s);
         }
