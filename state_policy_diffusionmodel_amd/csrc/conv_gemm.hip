@@ -617,12 +617,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 // -------------------------------------------------------------------------------------------------
 // Launch configurations.  cfg 0: 4 waves, 128 x {64,128}, one tap per barrier (exact-fp32 path and
 // 1-tap GEMMs).  cfg 1: 8 waves, 256 x {64,128}, three taps per barrier (split path, 3x3 / 3x1 convs).
-static bool use_big_tile(int M, int taps, int split) { return split && taps != 1 && M >= 256; }
-
+// Tile choice is occupancy-aware: the 8-wave 256-row configuration only when it still yields enough
+// workgroups to cover the 256 CUs; otherwise 128-row tiles, and 64-wide instead of 128-wide tiles when even
+// those would leave CUs idle (small batches / coarse levels).
 GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
     GemmGeom g;
-    g.m_tile = use_big_tile(M, taps, split) ? 256 : 128;
-    g.n_tile = (N % 128 == 0) ? 128 : 64;
+    const int nt128 = (N % 128 == 0) ? N / 128 : 0;
+    const int nt_pref = nt128 ? nt128 : N / 64;
+    bool big = split && taps != 1 && M >= 256;
+    if (big && (long long)((M + 255) / 256) * nt_pref < 192) big = false;
+    g.m_tile = big ? 256 : 128;
+    g.n_tile = nt128 ? 128 : 64;
+    if (!big && nt128 && (long long)((M + 127) / 128) * nt128 < 192) g.n_tile = 64;
     g.n_tiles = N / g.n_tile;
     g.slots = stats_slots(HW, g.m_tile, g.n_tiles);
     return g;

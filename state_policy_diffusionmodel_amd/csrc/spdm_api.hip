@@ -589,8 +589,11 @@ struct Ctx {
     StatsBuf salloc(int HW, int C, int m_tile, int n_tiles) {
         StatsBuf sb;
         const int slots = stats_slots(HW, m_tile, n_tiles);
+        // reserve for the finest tiling any batch size can select (gemm_geometry is batch-dependent, the
+        // dry run that sizes the arena is not): 128-row x 64-wide tiles
+        const int slots_max = std::max(slots, stats_slots(HW, 128, std::max(1, C / 64)));
         size_t off = 0;
-        if (!h->arena.alloc(sizeof(double) * 2 * (size_t)B * slots, &off)) {
+        if (!h->arena.alloc(sizeof(double) * 2 * (size_t)B * slots_max, &off)) {
             if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
             return sb;
         }
@@ -664,7 +667,7 @@ struct Ctx {
     StatsBuf row_stats_alloc(int rows, int C, int n_tiles) {
         StatsBuf sb;
         size_t off = 0;
-        if (!h->arena.alloc(sizeof(double) * 2 * (size_t)rows * n_tiles, &off)) {
+        if (!h->arena.alloc(sizeof(double) * 2 * (size_t)rows * std::max(n_tiles, C / 64), &off)) {   // finest tiling
             if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
             return sb;
         }
@@ -698,7 +701,7 @@ struct Ctx {
         if (!err && !dry) check(launch_attention_auto(qkv.p, att.p, B, L, C, 4, s), "attention core");
         free(qkv);
         Tensor av = talloc(C, level);
-        const int nt_av = (C % 128 == 0) ? C / 128 : C / 64;      // n-tiles of the out_proj GEMM (gemm_geometry)
+        const int nt_av = gemm_geometry(rows, C, 1, 1, (h->split && C % 32 == 0) ? 1 : 0).n_tiles;   // n-tiles of the out_proj GEMM
         StatsBuf avs = row_stats_alloc(rows, C, nt_av);
         linear(att.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p, nullptr, nullptr, nullptr, avs.p);
         free(att);
