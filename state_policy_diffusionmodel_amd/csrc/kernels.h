@@ -106,4 +106,12 @@ hipError_t launch_attention(const float* qkv /*[B*L][3C]*/, float* out /*[B*L][C
                             int heads, hipStream_t s);        // VALU kernel (small L)
 hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s);  // MFMA kernel for L >= 32
 
+// ---- fused SelfAttention block for the C = 64 levels (sa_fused.hip) -------------------------------------
+bool sa_fused_supported(int L, int C);
+// w_hl: {Wqkv hi, lo, Wo hi, lo, W1 hi, lo, W2 hi, lo} as fp16 [rows][64], input axis permuted by perm16 inside
+// each group of 16, pre-scaled by 128 (spdm_api.hip: Loader::perm_split)
+hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
+                             const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
+                             const float* bo, const float* b1, const float* b2, hipStream_t s);
+
 }  // namespace spdm

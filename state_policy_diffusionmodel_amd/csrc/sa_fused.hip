@@ -1,0 +1,369 @@
+// sa_fused.hip -- the whole SelfAttention block (models/Unet_FiLmLayer.py:71-82) of one trajectory in
+// ONE kernel, for the C = 64 levels (sa5: L = H/2 * 4, sa6: L = H * 8 tokens; L <= 256):
+//
+//   ln  = LayerNorm(x)                     qkv = ln W_in^T + b_in
+//   o_h = softmax(q_h k_h^T / sqrt d) v_h  (4 heads, d = 16)
+//   av  = [o_0..o_3] W_o^T + b_o + x       out = GELU(LayerNorm(av) W_1^T + b_1) W_2^T + b_2 + av
+//
+// Everything is computed TRANSPOSED -- features on the MFMA rows (accumulator registers), tokens on the
+// MFMA columns (lanes): Z^T = W Y^T.  One wave owns 32 tokens; lane l and lane l^32 hold the same token
+// and complementary feature rows ((reg&3) + 8 (reg>>2) + 4 (l>>5) inside each 32-row tile).  With that
+// orientation
+//   * a 32x32 accumulator tile IS the B operand of the next product (its rows are the summed index):
+//     registers 8s..8s+7 are the fragment of k-step s, so LN -> QKV -> out-proj -> LN -> FF1 -> GELU -> FF2
+//     chain through registers with no LDS or HBM round trip; residuals stay in registers too;
+//   * LayerNorm and softmax are per-lane register reductions plus one cross-half shuffle;
+//   * the weights are the A operands, read as 16-byte fragments straight from L2 (98 KB per layer).
+// Element j of lane half h in k-step s is row 16 s + 8 (j>>2) + 4 h + (j&3) of the producing tile; the host
+// stores every weight matrix with its input-feature axis permuted by that map inside each group of 16
+// (perm16 = 0 1 2 3 8 9 10 11 | 4 5 6 7 12 13 14 15) so a fragment is 16 contiguous bytes.
+// Only K and V^T of the current head go through LDS (shared by the waves of the trajectory):
+// 2 workgroup barriers per head.  All products use the split-fp16 scheme of conv_gemm.hip (fp16 hi + lo of
+// the pre-scaled operand, three v_mfma_f32_32x32x16_f16, fp32 accumulate): activations x16, weights x128,
+// probabilities x1024.
+#include <algorithm>
+
+#include "device_utils.h"
+
+namespace spdm {
+
+typedef float s_f32x16 __attribute__((ext_vector_type(16)));
+typedef float s_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 s_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 s_f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SA_C = 64, SA_D = 16, SA_HEADS = 4;
+constexpr int SA_KROW = 24;          // halfs per K row in LDS (16 + 8 pad: conflict-free ds_read_b128)
+constexpr float SA_DESCALE = 1.0f / 2048.0f;      // act x16, weight x128
+
+struct SaFusedArgs {
+    const float* x; float* out; int L;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const _Float16 *wqkv_h, *wqkv_l, *wo_h, *wo_l, *w1_h, *w1_l, *w2_h, *w2_l;   // [rows][64], permuted, x128
+    const float *bqkv, *bo, *b1, *b2;
+};
+
+__device__ __forceinline__ void sa_split(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+__device__ __forceinline__ float sa_exp_neg(float x) {
+    const float t = x * 1.44269504f;
+    const float tl = __fmaf_rn(x, 1.44269504f, -t) + x * 1.925963033e-8f;
+    return __builtin_amdgcn_exp2f(t) * (1.0f + tl * 0.69314718f);
+}
+// B fragments (k-steps 2T, 2T+1) of a 2-tile activation set z[2] (C = 64 features), pre-scale 16
+__device__ __forceinline__ void sa_make_frags(const s_f32x16 (&z)[2], s_f16x8 (&bh)[4], s_f16x8 (&bl)[4]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l;
+                sa_split(z[T][8 * s + j] * 16.0f, h, l);
+                bh[2 * T + s][j] = h;
+                bl[2 * T + s][j] = l;
+            }
+}
+// acc (+)= W[row0 + li][0..63] . B   (one 32-row output tile, K = 64 = 4 k-steps)
+__device__ __forceinline__ s_f32x16 sa_gemm_tile(const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, int row0,
+                                                  int li, int kh, const s_f16x8 (&bh)[4], const s_f16x8 (&bl)[4], s_f32x16 acc) {
+    const _Float16* ph = Wh + (size_t)(row0 + li) * SA_C + 8 * kh;
+    const _Float16* pl = Wl + (size_t)(row0 + li) * SA_C + 8 * kh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const s_f16x8 ah = *reinterpret_cast<const s_f16x8*>(ph + 16 * ks);
+        const s_f16x8 al = *reinterpret_cast<const s_f16x8*>(pl + 16 * ks);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
+    }
+    return acc;
+}
+// z[T][r] -> z * DESCALE + bias[feature]   (feature of register r in tile T: 32 T + (r&3) + 8 (r>>2) + 4 kh)
+__device__ __forceinline__ void sa_bias(s_f32x16& z, const float* __restrict__ bias, int T, int kh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const s_f32x4 b = *reinterpret_cast<const s_f32x4*>(bias + 32 * T + 8 * g + 4 * kh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[4 * g + j] = z[4 * g + j] * SA_DESCALE + b[j];
+    }
+}
+// LayerNorm over the 64 features of this lane's token (two-pass, like torch): z -> (z - mean) rstd gamma + beta
+__device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&y)[2], const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, int kh) {
+    float s = 0.f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += z[T][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = z[T][r] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const s_f32x4 ga = *reinterpret_cast<const s_f32x4*>(gamma + 32 * T + 8 * g + 4 * kh);
+            const s_f32x4 be = *reinterpret_cast<const s_f32x4*>(beta + 32 * T + 8 * g + 4 * kh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[T][4 * g + j] = (z[T][4 * g + j] - mean) * rstd * ga[j] + be[j];
+        }
+}
+
+__global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
+    const int L = a.L;
+    const int nwave = blockDim.x >> 6;
+    const int Lp = nwave * 32;
+    const int VROW = Lp + 4;                       // halfs per V^T row
+    _Float16* Khi = reinterpret_cast<_Float16*>(sa_smem);
+    _Float16* Klo = Khi + (size_t)Lp * SA_KROW;
+    _Float16* Vhi = Klo + (size_t)Lp * SA_KROW;    // [32][VROW], rows 16..31 stay zero
+    _Float16* Vlo = Vhi + (size_t)32 * VROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.x;
+    const int t = wave * 32 + li;                  // this lane's token
+    const int tc = min(t, L - 1);
+    const float* xrow = a.x + ((size_t)b * L + tc) * SA_C;
+
+    // zero rows 16..31 of V^T once (never overwritten): the d = 16 heads fill only half of a 32-row A tile
+    for (int i = tid; i < 16 * VROW; i += blockDim.x) {
+        Vhi[16 * VROW + i] = (_Float16)0.f;
+        Vlo[16 * VROW + i] = (_Float16)0.f;
+    }
+
+    // ---- x^T tiles of this token: register r of tile T = feature 32 T + (r&3) + 8 (r>>2) + 4 kh ----
+    s_f32x16 xt[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const s_f32x4 v = *reinterpret_cast<const s_f32x4*>(xrow + 32 * T + 8 * g + 4 * kh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xt[T][4 * g + j] = v[j];
+        }
+
+    // ---- LayerNorm 1 and its B fragments ----
+    s_f16x8 bh[4], bl[4];
+    {
+        s_f32x16 ln[2];
+        sa_layernorm(xt, ln, a.ln1_g, a.ln1_b, kh);
+        sa_make_frags(ln, bh, bl);
+    }
+
+    s_f32x16 av[2];                                // out-proj accumulator (scaled by 2048 until the end)
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) av[T][r] = 0.f;
+
+    // ---- two head pairs: tile p of Q, K, V rows holds heads 2p (rows 0..15) and 2p+1 (rows 16..31) ----
+    for (int p = 0; p < 2; ++p) {
+        s_f32x16 qt, kt, vt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { qt[r] = 0.f; kt[r] = 0.f; vt[r] = 0.f; }
+        qt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 32 * p, li, kh, bh, bl, qt);
+        kt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 64 + 32 * p, li, kh, bh, bl, kt);
+        vt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 128 + 32 * p, li, kh, bh, bl, vt);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const s_f32x4 bq = *reinterpret_cast<const s_f32x4*>(a.bqkv + 32 * p + 8 * g + 4 * kh);
+            const s_f32x4 bk = *reinterpret_cast<const s_f32x4*>(a.bqkv + 64 + 32 * p + 8 * g + 4 * kh);
+            const s_f32x4 bv = *reinterpret_cast<const s_f32x4*>(a.bqkv + 128 + 32 * p + 8 * g + 4 * kh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qt[4 * g + j] = (qt[4 * g + j] * SA_DESCALE + bq[j]) * 0.25f;      // 1/sqrt(16), applied to q like torch
+                kt[4 * g + j] = kt[4 * g + j] * SA_DESCALE + bk[j];
+                vt[4 * g + j] = vt[4 * g + j] * SA_DESCALE + bv[j];
+            }
+        }
+
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int head = 2 * p + sub;
+            // registers 8 sub .. 8 sub + 7 are this head's 16 features (8 per lane half, in fragment order)
+            s_f16x8 q_h, q_l, k_h, k_l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l;
+                sa_split(qt[8 * sub + j] * 16.0f, h, l);
+                q_h[j] = h; q_l[j] = l;
+                sa_split(kt[8 * sub + j] * 16.0f, h, l);
+                k_h[j] = h; k_l[j] = l;
+            }
+            __syncthreads();                        // every wave is done with the previous head's K / V^T
+            *reinterpret_cast<s_f16x8*>(Khi + t * SA_KROW + 8 * kh) = k_h;
+            *reinterpret_cast<s_f16x8*>(Klo + t * SA_KROW + 8 * kh) = k_l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {           // V^T[d][token], d = 8 (j>>2) + 4 kh + (j&3)
+                _Float16 h, l;
+                sa_split(vt[8 * sub + j] * 16.0f, h, l);
+                const int dd = 8 * (j >> 2) + 4 * kh + (j & 3);
+                Vhi[dd * VROW + t] = h;
+                Vlo[dd * VROW + t] = l;
+            }
+            __syncthreads();
+
+            // ---- flash attention of this wave's 32 queries over all key blocks ----
+            s_f32x16 acc_o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
+            float m = -1e30f, lsum = 0.f;
+            for (int kb = 0; kb < nwave; ++kb) {
+                s_f32x16 acc_s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
+                const s_f16x8 ka_h = *reinterpret_cast<const s_f16x8*>(Khi + (kb * 32 + li) * SA_KROW + 8 * kh);
+                const s_f16x8 ka_l = *reinterpret_cast<const s_f16x8*>(Klo + (kb * 32 + li) * SA_KROW + 8 * kh);
+                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_h, q_h, acc_s, 0, 0, 0);
+                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_h, q_l, acc_s, 0, 0, 0);
+                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_l, q_h, acc_s, 0, 0, 0);
+                float sc[16];
+                float mloc = -1e30f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    sc[r] = (key < L) ? acc_s[r] * (1.0f / 256.0f) : -1e30f;
+                    mloc = fmaxf(mloc, sc[r]);
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float m_new = fmaxf(m, mloc);
+                const float alpha = sa_exp_neg(m - m_new);
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sc[r] = sa_exp_neg(sc[r] - m_new);
+                    psum += sc[r];
+                }
+                lsum = lsum * alpha + psum;
+                m = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    s_f16x8 p_h, p_l;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        _Float16 h, l;
+                        sa_split(sc[8 * s2 + j] * 1024.0f, h, l);
+                        p_h[j] = h; p_l[j] = l;
+                    }
+                    const _Float16* vr_h = Vhi + li * VROW + kb * 32 + 16 * s2 + 4 * kh;
+                    const _Float16* vr_l = Vlo + li * VROW + kb * 32 + 16 * s2 + 4 * kh;
+                    const s_f16x4 vh0 = *reinterpret_cast<const s_f16x4*>(vr_h), vh1 = *reinterpret_cast<const s_f16x4*>(vr_h + 8);
+                    const s_f16x4 vl0 = *reinterpret_cast<const s_f16x4*>(vr_l), vl1 = *reinterpret_cast<const s_f16x4*>(vr_l + 8);
+                    const s_f16x8 v_h = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+                    const s_f16x8 v_l = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+                    acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_h, acc_o, 0, 0, 0);
+                    acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_l, acc_o, 0, 0, 0);
+                    acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h, acc_o, 0, 0, 0);
+                }
+            }
+            lsum += __shfl_xor(lsum, 32, 64);
+            const float inv = 1.0f / (lsum * 16384.0f);        // p x1024, v x16
+
+            // ---- out-proj: av^T += W_o[:, 16 head .. 16 head + 15] . o_head^T  (one k-step; o rows = registers 0..7) ----
+            s_f16x8 o_h, o_l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l;
+                sa_split((acc_o[j] * inv) * 16.0f, h, l);
+                o_h[j] = h; o_l[j] = l;
+            }
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const s_f16x8 ah = *reinterpret_cast<const s_f16x8*>(a.wo_h + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
+                const s_f16x8 al = *reinterpret_cast<const s_f16x8*>(a.wo_l + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
+                av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, o_h, av[T], 0, 0, 0);
+                av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, o_l, av[T], 0, 0, 0);
+                av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, o_h, av[T], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- av = out_proj + b_o + x ----
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        sa_bias(av[T], a.bo, T, kh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) av[T][r] += xt[T][r];
+    }
+    // ---- feed-forward: LN -> W1 -> GELU -> W2 -> + av ----
+    {
+        s_f32x16 ln[2];
+        sa_layernorm(av, ln, a.ln2_g, a.ln2_b, kh);
+        sa_make_frags(ln, bh, bl);
+    }
+    s_f32x16 f[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
+        f[T] = sa_gemm_tile(a.w1_h, a.w1_l, 32 * T, li, kh, bh, bl, f[T]);
+        sa_bias(f[T], a.b1, T, kh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[T][r] = gelu_erf(f[T][r]);
+    }
+    sa_make_frags(f, bh, bl);
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
+        f[T] = sa_gemm_tile(a.w2_h, a.w2_l, 32 * T, li, kh, bh, bl, f[T]);
+        sa_bias(f[T], a.b2, T, kh);
+    }
+    if (t < L) {
+        float* orow = a.out + ((size_t)b * L + t) * SA_C;
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const s_f32x4 v = {f[T][4 * g] + av[T][4 * g], f[T][4 * g + 1] + av[T][4 * g + 1],
+                                   f[T][4 * g + 2] + av[T][4 * g + 2], f[T][4 * g + 3] + av[T][4 * g + 3]};
+                *reinterpret_cast<s_f32x4*>(orow + 32 * T + 8 * g + 4 * kh) = v;
+            }
+    }
+}
+
+bool sa_fused_supported(int L, int C) { return C == SA_C && L >= 1 && L <= 256; }
+
+hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
+                             const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
+                             const float* bo, const float* b1, const float* b2, hipStream_t s) {
+    if (!sa_fused_supported(L, SA_C) || B <= 0) return hipErrorInvalidValue;
+    SaFusedArgs a{};
+    a.x = x; a.out = out; a.L = L;
+    a.ln1_g = ln1_g; a.ln1_b = ln1_b; a.ln2_g = ln2_g; a.ln2_b = ln2_b;
+    a.wqkv_h = (const _Float16*)w_hl[0]; a.wqkv_l = (const _Float16*)w_hl[1];
+    a.wo_h = (const _Float16*)w_hl[2]; a.wo_l = (const _Float16*)w_hl[3];
+    a.w1_h = (const _Float16*)w_hl[4]; a.w1_l = (const _Float16*)w_hl[5];
+    a.w2_h = (const _Float16*)w_hl[6]; a.w2_l = (const _Float16*)w_hl[7];
+    a.bqkv = bqkv; a.bo = bo; a.b1 = b1; a.b2 = b2;
+    const int nwave = (L + 31) / 32;
+    const int Lp = nwave * 32;
+    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 4)) * sizeof(_Float16);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused64_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(sa_fused64_kernel, dim3(B), dim3(64 * nwave), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace spdm

@@ -114,7 +114,12 @@ struct ConvW { float* w = nullptr; float* ws = nullptr; int taps = 0, cin = 0, c
 struct DoubleConvW { ConvW first, second; float* gamma = nullptr; float* beta = nullptr; };
 struct LinW { float* w = nullptr; float* ws = nullptr; float* b = nullptr; int in = 0, out = 0; };
 struct ResampleW { DoubleConvW dc1, dc2; LinW emb, film; float* temb_table = nullptr; int cout = 0; };
-struct AttnW { LinW in_proj, out_proj, ff1, ff2; float* ln_g = nullptr; float* ln_b = nullptr; float* ff_ln_g = nullptr; float* ff_ln_b = nullptr; int C = 0; };
+struct AttnW {
+    LinW in_proj, out_proj, ff1, ff2;
+    float* ln_g = nullptr; float* ln_b = nullptr; float* ff_ln_g = nullptr; float* ff_ln_b = nullptr;
+    int C = 0;
+    void* fw[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fused-kernel weights (C == 64)
+};
 
 struct ProfEvt { hipEvent_t a, b; double flops; };
 
@@ -437,9 +442,42 @@ struct Loader {
         r.cout = cout;
         return r;
     }
+    // (out, 64) fp32 -> two fp16 arrays [out][64] (hi, lo of 128 x), input axis permuted inside each group of 16 by
+    // perm16 = 0 1 2 3 8 9 10 11 | 4 5 6 7 12 13 14 15: the k-slot order of an accumulator tile used as B operand
+    // (sa_fused.hip)
+    void perm_split(const std::string& wname, int out, void** hi_dev, void** lo_dev) {
+        static const int perm16[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
+        const float* w = find(wname, {out, 64});
+        if (!w) return;
+        std::vector<_Float16> hi((size_t)out * 64), lo((size_t)out * 64);
+        for (int o = 0; o < out; ++o)
+            for (int g = 0; g < 4; ++g)
+                for (int pos = 0; pos < 16; ++pos) {
+                    const float x = w[(size_t)o * 64 + 16 * g + perm16[pos]] * 128.0f;
+                    const _Float16 h16 = (_Float16)x;
+                    hi[(size_t)o * 64 + 16 * g + pos] = h16;
+                    lo[(size_t)o * 64 + 16 * g + pos] = (_Float16)(x - (float)h16);
+                }
+        for (int which = 0; which < 2; ++which) {
+            void* d = nullptr;
+            const std::vector<_Float16>& src = which ? lo : hi;
+            if (dev_alloc(h, &d, src.size() * sizeof(_Float16)) != SPDM_OK) { err = SPDM_ERR_HIP; return; }
+            if (hipMemcpy(d, src.data(), src.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) {
+                err = fail(SPDM_ERR_HIP, "weight upload failed");
+                return;
+            }
+            *(which ? lo_dev : hi_dev) = d;
+        }
+    }
     AttnW attn(const std::string& p, int C) {
         AttnW a;
         a.C = C;
+        if (C == 64) {
+            perm_split(p + ".attention.in_proj_weight", 192, &a.fw[0], &a.fw[1]);
+            perm_split(p + ".attention.out_proj.weight", 64, &a.fw[2], &a.fw[3]);
+            perm_split(p + ".ff_self.1.weight", 64, &a.fw[4], &a.fw[5]);
+            perm_split(p + ".ff_self.3.weight", 64, &a.fw[6], &a.fw[7]);
+        }
         a.in_proj = linear(p + ".attention.in_proj_weight", p + ".attention.in_proj_bias", 3 * C, C, C);
         a.out_proj = linear(p + ".attention.out_proj.weight", p + ".attention.out_proj.bias", C, C, C);
         a.ln_g = vec(p + ".ln.weight", C);
@@ -692,8 +730,20 @@ struct Ctx {
     // SelfAttention.forward, models/Unet_FiLmLayer.py:71-82.  Consumes x (and its per-token LayerNorm
     // statistics xs, produced by film_apply), returns the block output.  Both LayerNorms run as the load
     // prologue of the GEMM that consumes them: self.ln -> in_proj, ff_self[0] -> ff_self[1].
+    bool sa_fused(const AttnW& w, int level) const {
+        return h->split && sa_fused_supported(HWl(level), w.C) && getenv("SPDM_NO_SA_FUSED") == nullptr;
+    }
     Tensor attention(Tensor& x, StatsBuf& xs, const AttnW& w, int level) {
         const int L = HWl(level), rows = B * L, C = w.C;
+        if (sa_fused(w, level)) {            // whole block in one kernel (sa_fused.hip)
+            Tensor out = talloc(C, level);
+            if (!err && !dry)
+                check(launch_sa_fused64(x.p, out.p, B, L, w.ln_g, w.ln_b, w.ff_ln_g, w.ff_ln_b, w.fw, w.in_proj.b,
+                                        w.out_proj.b, w.ff1.b, w.ff2.b, s), "fused attention block");
+            free(x);
+            free(xs);
+            return out;
+        }
         Tensor qkv = ralloc(rows, 3 * C);
         linear(x.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr, &xs, w.ln_g, w.ln_b);
         free(xs);
@@ -764,7 +814,8 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         Value a = c.double_conv(p, h->down[i].dc1, lout);
         Value b2 = c.double_conv(a, h->down[i].dc2, lout);
         StatsBuf ys;
-        Tensor y = c.film_tail(b2, h->down[i], i, lout, use_cond, h->cfg.attention ? &ys : nullptr);
+        Tensor y = c.film_tail(b2, h->down[i], i, lout, use_cond,
+                               (h->cfg.attention && !c.sa_fused(h->sa[i], lout)) ? &ys : nullptr);
         c.tap(dn[i], y);
         if (h->cfg.attention) y = c.attention(y, ys, h->sa[i], lout);
         c.tap(xn[i], y);
@@ -798,7 +849,8 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         Value a = c.double_conv(cat, h->up[i].dc1, lout);
         Value b3 = c.double_conv(a, h->up[i].dc2, lout);
         StatsBuf ys;
-        Tensor y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond, h->cfg.attention ? &ys : nullptr);
+        Tensor y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond,
+                               (h->cfg.attention && !c.sa_fused(h->sa[3 + i], lout)) ? &ys : nullptr);
         c.tap(un[i], y);
         if (h->cfg.attention) y = c.attention(y, ys, h->sa[3 + i], lout);
         c.tap(an[i], y);
