@@ -188,6 +188,12 @@ def main():
         peak = 2516.6 if split else 157.3
         kernel = ("conv_gemm_kernel (3x3 implicit GEMM; split-fp16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per K=16, fp32 accumulate)"
                   if split else "conv_gemm_kernel (3x3 implicit GEMM; v_mfma_f32_32x32x2_f32)")
+        traffic = None      # HBM bytes per launch of the same kernel class, from the committed rocprofv3 PMC passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")) as fh:
+                traffic = float(json.load(fh)["traffic_bytes_per_launch"])
+        except Exception:
+            pass
         line = {
             "metric": "denoise-steps/sec (B=4096, horizon=32)",
             "value": value, "unit": "trajectory-steps/s",
@@ -202,7 +208,8 @@ def main():
                        "global_batch": world * B, "horizon": H, "state_dim": D, "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "algorithmic_fp32_equiv_tflops": algo, "fp32_mfma_peak_tflops": 157.3,
+                         "traffic": traffic, "traffic_source": "profiles/r01_roofline_traffic.json (rocprofv3 PMC, B=4096)" if traffic else None,
+                         "algorithmic_fp32_equiv_tflops": algo, "fp32_mfma_peak_tflops": 157.3,
                          "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "share_of_step_time": conv_ms / (el * 1e3)},
         }
