@@ -629,6 +629,10 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
     g.m_tile = big ? 256 : 128;
     g.n_tile = nt128 ? 128 : 64;
     if (!big && nt128 && (long long)((M + 127) / 128) * nt128 < 192) g.n_tile = 64;
+    // 64-wide outputs: 512-row tiles keep 72 MFMAs per wave between barriers (8 waves x 64x64)
+    if (big && g.n_tile == 64 && taps == 9 && (long long)((M + 511) / 512) * (N / 64) >= 192 &&
+        getenv("SPDM_NO_T512") == nullptr)
+        g.m_tile = 512;
     g.n_tiles = N / g.n_tile;
     g.slots = stats_slots(HW, g.m_tile, g.n_tiles);
     return g;
@@ -681,6 +685,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
             if (g.n_tile == 128) return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 2, 1>(a, g, s);
             return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 1, 1>(a, g, s);
         }
+        if (g.m_tile == 512) return launch_cfg<true, PREC_SPLIT, 8, 1, 2, 2, 3>(a, g, s);
         if (g.m_tile == 256) {
             if (a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && getenv("SPDM_NO_W2") == nullptr) {   // level-2 maps: zero-tap skipping
                 if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3, true>(a, g, s);
