@@ -83,6 +83,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     constexpr int WPASS = N_T / RP;                                  // per tap
     constexpr int NBA = (TPI == 1) ? 2 : 1;                          // A slab buffers
     constexpr bool PP = (NTHR == 512);                               // ping-pong schedule (see main loop)
+    // WDMA (experiment, OFF): weight slabs global -> LDS by LDS-DMA (global_load_lds_dwordx4; un-padded rows,
+    // XOR swizzle of the 16-byte chunk with (row>>1)&7 on the per-lane source address and on the fragment
+    // reads), issued by waves 0-3 only.  Measured on MI355X: numerically identical, 18 fewer VGPRs, SAME kernel
+    // time -- in-kernel stamps show each LDS-DMA wave instruction costing 250-430 cycles of issue while the
+    // MFMA/LDS pipes are busy, i.e. the CU's vector-memory path (48 KB of weights per 4608 MFMA cycles), not the
+    // instruction mix of the staging, is the co-limiter.  Left in for tile-shape experiments (-DSPDM_WDMA).
+#ifdef SPDM_WDMA
+    constexpr bool WDMA = (NTHR == 512) && (PREC == PREC_SPLIT);
+#else
+    constexpr bool WDMA = false;
+#endif
+    constexpr int WROW = WDMA ? 32 : LDK;                            // floats per W row in LDS
     static_assert(!PP || NBA == 1, "ping-pong uses the single-slab hand-over");
     // W2: image width 2 (level-2 maps).  A third of the (position, tap) pairs of a 3x3 kernel then hit zero
     // padding: for w = 0 the dw = -1 column, for w = 1 the dw = +1 column.  Each wave's 64 rows are PERMUTED so
@@ -112,8 +124,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     const int m0 = mtile * M_T, n0 = ntile * N_T;
 
     float* Abuf = smem;                                   // [NBA][QZ][LDK]
-    float* Wbuf = Abuf + NBA * QZ * LDK;                  // [2][TPI][N_T][LDK]
-    float* smean = Wbuf + 2 * TPI * N_T * LDK;            // [NSP]
+    float* Wbuf = Abuf + NBA * QZ * LDK;                  // [2][TPI][N_T][WROW]
+    float* smean = Wbuf + 2 * TPI * N_T * WROW;           // [NSP]
     float* srstd = smean + NSP;                           // [NSP]
 
     // diagnostic stamps (DBG_STAMP): thread 0 of each half of the workgroup that owns logical tile 37
@@ -197,7 +209,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     }
     const int zoff = QA * LDK + koff;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) boff[nt] = (wn * NT * 32 + nt * 32 + li) * LDK + koff;
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = (wn * NT * 32 + nt * 32 + li) * WROW + (WDMA ? 0 : koff);
+    const int swz = (li >> 1) & 7;            // WDMA: chunk swizzle of this lane's W rows ((row>>1)&7; rows are 32-aligned + li)
+    // float offset of the 16-byte fragment (k-step s2, hi/lo) inside a W row
+#define SPDM_WOFF(s2_, lo_) (WDMA ? (((((lo_) ? 4 : 0) + 2 * (s2_) + kh) ^ swz) << 2) : ((s2_) * 8 + ((lo_) ? 16 : 0)))
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     // loads (rows outside the tensor are clamped to a valid address and zeroed at LDS-write time):
     // a predicated load makes hipcc wait for it right where it is issued, and HIP's float4 struct
     // arrays end up in scratch -- both defeat the overlap of the loads with the MFMA block.
-    f32x4 areg[APASS], wreg[TPI * WPASS];
+    f32x4 areg[APASS], wreg[WDMA ? 1 : TPI * WPASS];
     f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};   // GroupNorm gain / offset of this thread's 4 channels
 
 #define SPDM_LOAD_A(chunk_)                                                                         \
@@ -223,8 +238,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (chunk_) * CK + c4 * 4);             \
         }                                                                                           \
     }
+    const int gw = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, provably uniform
+    // per-lane part of the DMA source address: row (lane>>3) of the 8-row block, swizzled 16-byte chunk.  The
+    // swizzle key (row>>1)&7 of row = 8 blk + (lane>>3) is (4 (blk&1) + (lane>>4)) & 7, and blk&1 == gw&1 for
+    // every block a wave handles -> one offset register per lane.
+    const int dma_loff = (lane >> 3) * K + (((lane & 7) ^ ((4 * (gw & 1) + (lane >> 4)) & 7)) << 2);
+    // LDS-DMA of one W group slab (TPI taps x N_T rows x 128 B), by waves 0-3: each wave instruction moves
+    // 8 rows = 1 KiB (lane -> row lane>>3, physical chunk lane&7, source chunk = physical ^ ((row>>1)&7))
+#define SPDM_DMA_W(chunk_, tg_, buf_)                                                               \
+    if (gw < 4) {                                                                                   \
+        _Pragma("unroll") for (int blk_ = 0; blk_ < TPI * N_T / 32; ++blk_) {                      \
+            const int row0_ = (blk_ * 4 + gw) * 8;                 /* wave-uniform */               \
+            const int tp_ = row0_ / N_T, n_ = row0_ % N_T;                                          \
+            const float* sb_ = a.wgt + (size_t)(((tg_) * TPI + tp_) * N + n0 + n_) * K + (chunk_) * CK; \
+            float* dst_ = Wbuf + (buf_) * TPI * N_T * WROW + row0_ * 32;                            \
+            __builtin_amdgcn_global_load_lds(                                                       \
+                (const __attribute__((address_space(1))) void*)(sb_ + dma_loff),                    \
+                (__attribute__((address_space(3))) void*)(dst_), 16, 0, 0);                         \
+        }                                                                                           \
+    }
 #define SPDM_LOAD_W(chunk_, tg_)                                                                    \
-    {                                                                                               \
+    if (!WDMA) {                                                                                    \
         _Pragma("unroll") for (int tp_ = 0; tp_ < TPI; ++tp_) {                                    \
             const float* wb_ = wptr + (size_t)((tg_) * TPI + tp_) * N * K + (chunk_) * CK;          \
             _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                   \
@@ -232,7 +266,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
         }                                                                                           \
     }
 #define SPDM_STORE_W(buf_)                                                                          \
-    {                                                                                               \
+    if (!WDMA) {                                                                                    \
         float* wd_ = Wbuf + (buf_) * TPI * N_T * LDK + srow_t * LDK + c4 * 4;                       \
         _Pragma("unroll") for (int tp_ = 0; tp_ < TPI; ++tp_)                                      \
             _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                   \
@@ -285,6 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     const int niter = nchunks * ngroups;
 
     SPDM_LOAD_A(0)
+    if (WDMA) SPDM_DMA_W(0, 0, 0)
     SPDM_LOAD_W(0, 0)
     SPDM_TRANSFORM_A()
     SPDM_WRITE_A(0)
@@ -297,7 +332,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 #define SPDM_MFMA_BLOCK(chunk_, tg_, wbuf_)                                                         \
     {                                                                                               \
         const float* Ab = Abuf + (NBA == 2 ? ((chunk_) & 1) : 0) * QZ * LDK;                        \
-        const float* Wb = Wbuf + (wbuf_) * TPI * N_T * LDK;                                         \
+        const float* Wb = Wbuf + (wbuf_) * TPI * N_T * WROW;                                        \
         const float* ap[TPI][MT];                                                                   \
         _Pragma("unroll") for (int tp = 0; tp < TPI; ++tp) {                                       \
             const int tap = (tg_) * TPI + tp;                                                       \
@@ -322,8 +357,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                     fa[set][0] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + s2 * 8);              \
                     fa[set][1] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + 16 + s2 * 8);         \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                            \
-                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + s2 * 8);      \
-                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + 16 + s2 * 8); \
+                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * WROW + boff[nt] + SPDM_WOFF(s2, 0)); \
+                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * WROW + boff[nt] + SPDM_WOFF(s2, 1)); \
                     }                                                                               \
                 }                                                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
@@ -351,8 +386,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                         fa[set][mt][1] = *reinterpret_cast<const f16x8*>(ap[tp][mt] + 16 + s2 * 8); \
                     }                                                                               \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                            \
-                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + s2 * 8);      \
-                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * LDK + boff[nt] + 16 + s2 * 8); \
+                        fb[set][nt][0] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * WROW + boff[nt] + SPDM_WOFF(s2, 0)); \
+                        fb[set][nt][1] = *reinterpret_cast<const f16x8*>(Wb + tp * N_T * WROW + boff[nt] + SPDM_WOFF(s2, 1)); \
                     }                                                                               \
                 }                                                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
@@ -374,7 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
                         av[mt] = *reinterpret_cast<const f32x4*>(ap[tp][mt] + g * 8);               \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                              \
-                        bv[nt] = *reinterpret_cast<const f32x4*>(Wb + tp * N_T * LDK + boff[nt] + g * 8); \
+                        bv[nt] = *reinterpret_cast<const f32x4*>(Wb + tp * N_T * WROW + boff[nt] + g * 8); \
                     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                        \
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0); \
@@ -445,7 +480,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                     if (next_A) SPDM_LOAD_A(nchunk)
                 }
             }
-            if (have_next && !(dbg & DBG_NO_WLOAD)) SPDM_LOAD_W(nchunk, ntg)
+            if (have_next && !(dbg & DBG_NO_WLOAD)) {
+                if (WDMA) SPDM_DMA_W(nchunk, ntg, (it + 1) & 1)
+                SPDM_LOAD_W(nchunk, ntg)
+            }
             if (early && next_A) SPDM_TRANSFORM_A()
             SPDM_STAMP()
             SPDM_MFMA_BLOCK(chunk, tg, it & 1)
@@ -464,6 +502,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
         }
     }
 #undef SPDM_MFMA_BLOCK
+#undef SPDM_DMA_W
+#undef SPDM_WOFF
 #undef SPDM_LOAD_A
 #undef SPDM_LOAD_W
 #undef SPDM_STORE_W
@@ -647,7 +687,13 @@ static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s
     const int halo = HALO ? a.W + 1 : 0;
     const int QA = M_T + 2 * halo;
     const int NSP = (QA + 4) & ~3;
-    size_t lds = (size_t)(NBA * (QA + 1) * LDK + 2 * TPI * N_T * LDK + 2 * NSP) * sizeof(float);
+#ifdef SPDM_WDMA
+    constexpr bool WDMA = (NTHR == 512) && (PREC == PREC_SPLIT);
+#else
+    constexpr bool WDMA = false;
+#endif
+    constexpr int WROW = WDMA ? 32 : LDK;
+    size_t lds = (size_t)(NBA * (QA + 1) * LDK + 2 * TPI * N_T * WROW + 2 * NSP) * sizeof(float);
     lds = std::max(lds, (size_t)(M_T * WN * 2 + M_T * N_T) * sizeof(float));     // epilogue staging: srow + output tile
     if (lds > 160 * 1024 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI, W2>;
