@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--no-attention", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-batch", type=int, default=64)
-    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
 
 
@@ -98,7 +98,7 @@ def cpu_baseline(args, sd, cond_dim):
         x = one_step(x, args.train_steps - 2 - n)
         n += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or n >= 50:
+        if el >= args.cpu_seconds or n >= 400:
             break
     return {"value": B * n / el, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement), batch {B}, {n} full denoise steps "

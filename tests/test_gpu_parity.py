@@ -35,9 +35,10 @@ def weights(cond_dim, seed, attention=True, sha=None):
     return _SD[key]
 
 
-def make_engine(H, D, cond_dim, B, sd, attention=True, T=1000, debug=False):
+def make_engine(H, D, cond_dim, B, sd, attention=True, T=1000, debug=False, exact_fp32=False):
     from state_policy_diffusionmodel_amd.engine import SpdmEngine
-    eng = SpdmEngine(H, D, cond_dim, max_batch=B, attention=attention, num_train_timesteps=T, debug=debug)
+    eng = SpdmEngine(H, D, cond_dim, max_batch=B, attention=attention, num_train_timesteps=T, debug=debug,
+                     exact_fp32=exact_fp32)
     eng.load_state_dict(sd)
     return eng
 
@@ -72,6 +73,43 @@ def test_unet_matches_reference_golden(path):
                     assert d <= TOL, (ref_name, d)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_both_contraction_paths_match_golden(exact):
+    """Default split-fp16 MFMA path and the exact fp32 MFMA path (SPDM_FLAG_EXACT_FP32) against the same
+    reference golden; the unfused attention path is exercised by the exact engine (fused kernel is split-only)."""
+    g = np.load(os.path.join(GOLDEN, "unet_h32d3_b2.npz"))
+    sd = weights(1350, 0, True, str(g["weights_sha256"]))
+    eng = make_engine(32, 3, 1350, 2, sd, True, exact_fp32=exact)
+    try:
+        assert eng.split_precision == (not exact)
+        got = eng.unet_forward(torch.from_numpy(g["x"]).cuda(), np.atleast_1d(g["t"][0]), torch.from_numpy(g["cond"]).cuda())
+        assert np.abs(got.cpu().numpy() - g["eps"][0]).max() <= TOL
+    finally:
+        eng.close()
+
+
+def test_unfused_fallbacks_match_fused_paths(monkeypatch):
+    """The fused SelfAttention kernel / MFMA attention / zero-tap skipping each have a plain fallback
+    (env switches); all must agree with the default build on the same input to fp32 rounding."""
+    g = np.load(os.path.join(GOLDEN, "unet_h32d3_b2.npz"))
+    sd = weights(1350, 0, True, str(g["weights_sha256"]))
+    x, cond = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["cond"]).cuda()
+    outs = []
+    for env in ({}, {"SPDM_NO_SA_FUSED": "1"}, {"SPDM_NO_SA_FUSED": "1", "SPDM_ATTN_VALU": "1"}, {"SPDM_NO_W2": "1", "SPDM_NO_T512": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = make_engine(32, 3, 1350, 2, sd, True)
+        try:
+            outs.append(eng.unet_forward(x, [500], cond).cpu().numpy())
+        finally:
+            eng.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for o in outs:
+        assert np.abs(o - g["eps"][0]).max() <= TOL
+        assert np.abs(o - outs[0]).max() <= 2e-5
 
 
 @pytest.mark.parametrize("H,D,B,attention,cond", [(24, 4, 5, True, True), (8, 1, 3, True, True),
