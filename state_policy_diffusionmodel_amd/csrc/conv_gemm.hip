@@ -678,7 +678,15 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
     return g;
 }
 
-double gemm_flops(const GemmArgs& a) { return 2.0 * (double)a.M * (double)a.N * (double)a.K * (double)a.taps; }
+// 2 x MACs the launch actually evaluates (the W = 2 zero-tap skipping runs 6 of the 9 taps)
+static bool uses_w2(const GemmArgs& a, const GemmGeom& g) {
+    return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && getenv("SPDM_NO_W2") == nullptr;
+}
+double gemm_flops(const GemmArgs& a) {
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split);
+    const double taps = uses_w2(a, g) ? 6.0 : (double)a.taps;
+    return 2.0 * (double)a.M * (double)a.N * (double)a.K * taps;
+}
 
 template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI, bool W2 = false>
 static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
@@ -733,7 +741,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         }
         if (g.m_tile == 512) return launch_cfg<true, PREC_SPLIT, 8, 1, 2, 2, 3>(a, g, s);
         if (g.m_tile == 256) {
-            if (a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && getenv("SPDM_NO_W2") == nullptr) {   // level-2 maps: zero-tap skipping
+            if (uses_w2(a, g)) {   // level-2 maps: zero-tap skipping
                 if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3, true>(a, g, s);
                 return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3, true>(a, g, s);
             }
