@@ -745,6 +745,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
                 if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3, true>(a, g, s);
                 return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3, true>(a, g, s);
             }
+            if (conv_wide_supported(a, g)) return launch_conv_wide(a, g, s);      // conv_wide.hip: 4 waves x 128x64, 2 workgroups / CU
             if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3>(a, g, s);
             return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3>(a, g, s);
         }

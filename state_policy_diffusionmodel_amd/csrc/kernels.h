@@ -54,6 +54,10 @@ struct GemmGeom { int m_tile, n_tile, n_tiles, slots; };
 GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split);
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
+// conv_wide.hip: the 4-wave / 128x64-per-wave configuration of the 3x3 implicit GEMM (256 x 128 tiles, two
+// workgroups per CU); launch_gemm routes to it when conv_wide_supported
+bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g);
+hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s);
 
 // ---- streaming / small kernels (elementwise.hip) -------------------------------------------
 // first conv, Cin = 1, fused zero-padding of the (H0, D) trajectory to (Hp, Wp)

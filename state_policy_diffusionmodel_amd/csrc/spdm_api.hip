@@ -1140,8 +1140,8 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     a.debug = debug;
     unsigned long long* d_stamps = nullptr;
     if (debug & DBG_STAMP) {
-        HIP_TRY(hipMalloc((void**)&d_stamps, 256 * 8));
-        HIP_TRY(hipMemset(d_stamps, 0, 256 * 8));
+        HIP_TRY(hipMalloc((void**)&d_stamps, (size_t)65536 * 8 * 8));      // conv_wide: 8 stamps per workgroup
+        HIP_TRY(hipMemset(d_stamps, 0, (size_t)65536 * 8 * 8));
         a.stamps = d_stamps;
     }
     hipEvent_t e0, e1;
@@ -1171,7 +1171,13 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
         }
     }
     ms_out[1] = maxdiff;
-    if (d_stamps) {      // print the stamp deltas of the traced workgroup (cycles between consecutive stamps)
+    if (d_stamps && getenv("SPDM_STAMP_DUMP")) {      // raw per-workgroup timeline of conv_wide (analysed offline)
+        std::vector<unsigned long long> hs((size_t)65536 * 8);
+        if (hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(getenv("SPDM_STAMP_DUMP"), "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
+        }
+        (void)hipFree(d_stamps);
+    } else if (d_stamps) {      // print the stamp deltas of the traced workgroup (cycles between consecutive stamps)
         unsigned long long hs[256];
         if (hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess) {
             for (int g = 0; g < 2; ++g) {

@@ -29,7 +29,7 @@ for n in names:
     out = []
     for dn, dv in DBG.items():
         if dn in ("stamp", "pp", "pp+stamp"):
-            if "--stamp" not in sys.argv:
+            if "--stamp" not in sys.argv or (dn != "stamp" and os.environ.get("SPDM_STAMP_DUMP")):
                 continue
         elif dn != "full" and "--ablate" not in sys.argv:
             continue
