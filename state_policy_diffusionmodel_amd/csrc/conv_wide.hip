@@ -14,9 +14,15 @@
 //     out of phase: one workgroup's prologue, slab hand-over, barrier waits and store tail overlap
 //     the other's MFMA blocks (the 8-wave configuration runs one workgroup per CU, all of whose
 //     waves stall together: measured 44-50 % matrix-pipe occupancy);
+//   * the WEIGHT fragments never touch LDS: the host stores a fragment-order copy of the split weights
+//     (frag_order_weights, kernels.h: one 1-KiB block per MFMA B operand, lane-contiguous), and each wave
+//     loads its B operands straight into registers with coalesced global_load_dwordx4, one K = 16
+//     half-tap (24 MFMAs) ahead; the waves of a workgroup then only meet at the slab hand-over (one
+//     barrier pair per 32-channel chunk = per 432 MFMAs, instead of one barrier per tap), and the MFMA
+//     stream of a chunk is unbroken;
 //   * the input slab for the next 32-channel chunk is loaded at the hand-over (the fragment
 //     registers are dead there) instead of being carried in registers across an MFMA block;
-//   * fragments are software-pipelined per 6-MFMA group (A: 2 x 2 registers sets, B: per K = 16 step);
+//   * A fragments are software-pipelined per 6-MFMA group across taps (2 x 2 register sets);
 //   * the epilogue goes through LDS in two 128-row halves.
 #include <algorithm>
 #include <cstdlib>
@@ -67,7 +73,6 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
     constexpr int RP = NTHR / 8;
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
     constexpr int APASS = (M_T + 18 + RP - 1) / RP;
-    constexpr int WPASS = N_T / RP;
     static_assert(APASS <= 16, "sample-index packing");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -88,8 +93,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
     const int m0 = mtile * M_T, n0 = ntile * N_T;
 
     float* Abuf = smem;                       // [QZ][LDK]
-    float* Wbuf = Abuf + QZ * LDK;            // [2][N_T][LDK]
-    float* smean = Wbuf + 2 * N_T * LDK;      // [NS]
+    float* smean = Abuf + QZ * LDK;           // [NS]
     float* srstd = smean + NS;                // [NS]
 
     // diagnostic builds: per-workgroup timeline {memrealtime, memtime x5, HW_ID, XCC_ID} (tools/bench_gemm.py --stamp)
@@ -104,9 +108,11 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
     const bool fine = (a.debug & DBG_STAMP) && a.stamps != nullptr && tid == 0 && bid == 700;
     int nfine = 0;
 #define WIDE_FINE() if (fine && nfine < 120) a.stamps[(size_t)40000 * 8 + nfine++] = (unsigned long long)__builtin_amdgcn_s_memtime();
+    const bool dbg_no_mfma = (a.debug & DBG_NO_MFMA) != 0, dbg_no_wload = (a.debug & DBG_NO_WLOAD) != 0;
 #else
 #define WIDE_STAMP(k_)
 #define WIDE_FINE()
+    constexpr bool dbg_no_mfma = false, dbg_no_wload = false;     // ablation knobs exist in diagnostic builds only
 #endif
     WIDE_STAMP(1)
     // Two workgroups share a CU.  Dispatched together, they would run in lock-step -- both in their MFMA loops,
@@ -152,10 +158,9 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
         }
     }
     const float* abase = a.src + c4 * 4;
-    const float* wptr = a.wgt + (size_t)(n0 + srow_t) * K + c4 * 4;   // + (tap N + p RP) K + chunk 32
 
     // ---- per-lane fragment rows and tap masks ----
-    int aoff[MT], boff[NT];
+    int aoff[MT];
     unsigned amask[MT];
     const int koff = kh * 4;
 #pragma unroll
@@ -177,8 +182,10 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
         amask[mt] = mask;
     }
     const int zoff = QA * LDK + koff;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) boff[nt] = (wn * NT * 32 + nt * 32 + li) * LDK + koff;
+    // B operands: fragment-order weights, block ((tap nchunks + chunk) N/32 + nb) x {s2} x {hi, lo} of 256 floats
+    const int nchunks = K / CK;
+    const float* wfl = a.wgt_frag + lane * 4;
+    const int nb0 = (n0 >> 5) + wn * NT;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    f32x4 areg[APASS], wreg[WPASS];
+    f32x4 areg[APASS];
     f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};
 
 #define WIDE_LOAD_A(chunk_)                                                                          \
@@ -229,28 +236,46 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
             if (pro) __builtin_amdgcn_sched_barrier(0);        /* one pass at a time: register pressure */ \
         }                                                                                            \
     }
-#define WIDE_LOAD_W(chunk_, tap_)                                                                    \
-    {                                                                                                \
-        const float* wb_ = wptr + (size_t)(tap_) * N * K + (chunk_) * CK;                            \
-        _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                        \
-            wreg[p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * RP * K);                   \
+#define WIDE_LOAD_B(set_, chunk_, tap_, s2_)                                                          \
+    if (!dbg_no_wload) {                                                                             \
+        const float* p_ = wfl + ((size_t)(((tap_) * nchunks + (chunk_)) * (N >> 5) + nb0) * 4 + (s2_) * 2) * 256; \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < NT; ++nt_) {                                      \
+            fb[set_][nt_][0] = *reinterpret_cast<const f16x8*>(p_ + nt_ * 1024);                     \
+            fb[set_][nt_][1] = *reinterpret_cast<const f16x8*>(p_ + nt_ * 1024 + 256);               \
+        }                                                                                            \
     }
-#define WIDE_STORE_W(buf_)                                                                           \
+#define WIDE_LOAD_FA(set_, ao_, s2_)                                                                 \
     {                                                                                                \
-        float* wd_ = Wbuf + (buf_) * N_T * LDK + srow_t * LDK + c4 * 4;                              \
-        _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                        \
-            *reinterpret_cast<f32x4*>(wd_ + p_ * RP * LDK) = wreg[p_];                               \
+        fa[set_][0] = *reinterpret_cast<const f16x8*>(Abuf + (ao_) + (s2_) * 8);                     \
+        fa[set_][1] = *reinterpret_cast<const f16x8*>(Abuf + (ao_) + 16 + (s2_) * 8);                \
+    }
+#define WIDE_TAP_OFFSETS(dst_, tap_)                                                                 \
+    {                                                                                                \
+        const int dh_ = (tap_) / 3 - 1, dw_ = (tap_) - ((tap_) / 3) * 3 - 1;                         \
+        const int shift_ = (dh_ * W + dw_) * LDK;                                                    \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)                                        \
+            dst_[mt_] = ((amask[mt_] >> (tap_)) & 1u) ? aoff[mt_] + shift_ : zoff;                   \
+    }
+#define WIDE_GROUP(set_, fbs_, mt_)                                                                  \
+    if (!dbg_no_mfma) {                                                                              \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < NT; ++nt_) {                                      \
+            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set_][0], fb[fbs_][nt_][0], acc[mt_][nt_], 0, 0, 0); \
+            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set_][0], fb[fbs_][nt_][1], acc[mt_][nt_], 0, 0, 0); \
+            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set_][1], fb[fbs_][nt_][0], acc[mt_][nt_], 0, 0, 0); \
+        }                                                                                            \
     }
 
-    const int nchunks = K / CK;
     const int niter = nchunks * 9;
 
+    f16x8 fa[2][2], fb[2][NT][2];
+    int ao[MT], aon[MT];
+    WIDE_LOAD_B(0, 0, 0, 0)
     WIDE_LOAD_A(0)
-    WIDE_LOAD_W(0, 0)
     WIDE_STAGE_A()
-    WIDE_STORE_W(0)
     __syncthreads();
     WIDE_STAMP(2)
+    WIDE_TAP_OFFSETS(ao, 0)
+    WIDE_LOAD_FA(0, ao[0], 0)
 
     int chunk = 0, tap = 0;
     for (int it = 0; it < niter; ++it) {
@@ -259,68 +284,49 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
         const bool have_next = (it + 1 < niter);
         const bool next_A = have_next && (ntap == 0);
         WIDE_FINE()
-        if (have_next) WIDE_LOAD_W(nchunk, ntap)
-        WIDE_FINE()
-
-        {   // ---- MFMA block of one tap: 2 K=16 steps x 4 row tiles = 8 groups of 6 MFMAs ----
-            const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
-            const int shift = (dh * W + dw) * LDK;
-            const float* Wb = Wbuf + (it & 1) * N_T * LDK;
-            int ao[MT];
+        // ---- K = 16 half-tap 0 (B set 0; the loads of set 1 fly meanwhile) ----
+        WIDE_LOAD_B(1, chunk, tap, 1)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ao[mt] = ((amask[mt] >> tap) & 1u) ? aoff[mt] + shift : zoff;
-            f16x8 fa[2][2], fb[2][NT][2];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                fb[0][nt][0] = *reinterpret_cast<const f16x8*>(Wb + boff[nt]);
-                fb[0][nt][1] = *reinterpret_cast<const f16x8*>(Wb + boff[nt] + 16);
-            }
-            fa[0][0] = *reinterpret_cast<const f16x8*>(Abuf + ao[0]);
-            fa[0][1] = *reinterpret_cast<const f16x8*>(Abuf + ao[0] + 16);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int s2 = g >> 2, mt = g & 3;
-                if (g + 1 < 8) {
-                    const int s2n = (g + 1) >> 2, mtn = (g + 1) & 3, setn = (g + 1) & 1;
-                    fa[setn][0] = *reinterpret_cast<const f16x8*>(Abuf + ao[mtn] + s2n * 8);
-                    fa[setn][1] = *reinterpret_cast<const f16x8*>(Abuf + ao[mtn] + 16 + s2n * 8);
-                    if (g + 1 == 4) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            fb[1][nt][0] = *reinterpret_cast<const f16x8*>(Wb + boff[nt] + 8);
-                            fb[1][nt][1] = *reinterpret_cast<const f16x8*>(Wb + boff[nt] + 16 + 8);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const int set = g & 1;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0], fb[s2][nt][0], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0], fb[s2][nt][1], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][1], fb[s2][nt][0], acc[mt][nt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt < MT - 1) WIDE_LOAD_FA((mt + 1) & 1, ao[mt + 1], 0) else WIDE_LOAD_FA(0, ao[0], 1)
+            __builtin_amdgcn_sched_barrier(0);
+            WIDE_GROUP(mt & 1, 0, mt)
+            __builtin_amdgcn_sched_barrier(0);
         }
-
         WIDE_FINE()
-        if (have_next) WIDE_STORE_W((it + 1) & 1)
+        // ---- half-tap 1 (B set 1; set 0 is refilled for the next tap) ----
+        // unconditional (the last iteration re-reads its own block): a branch here would make the compiler wait
+        // with vmcnt(0), i.e. for these loads too, before the MFMAs of this half-tap
+        WIDE_LOAD_B(0, (have_next ? nchunk : chunk), (have_next ? ntap : tap), 0)
+        WIDE_TAP_OFFSETS(aon, ntap)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt < MT - 1) WIDE_LOAD_FA((mt + 1) & 1, ao[mt + 1], 1) else if (have_next && !next_A) WIDE_LOAD_FA(0, aon[0], 0)
+            __builtin_amdgcn_sched_barrier(0);
+            WIDE_GROUP(mt & 1, 1, mt)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         WIDE_FINE()
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ao[mt] = aon[mt];
         if (next_A) {
             WIDE_LOAD_A(nchunk)             // in flight across the barrier
             __syncthreads();                // every wave is done reading the slab of this chunk
             WIDE_STAGE_A()
+            __syncthreads();
+            WIDE_LOAD_FA(0, ao[0], 0)
         }
-        __syncthreads();
+        WIDE_FINE()
         tap = ntap;
         chunk = nchunk;
     }
-    WIDE_STAMP(3)
 #undef WIDE_LOAD_A
 #undef WIDE_STAGE_A
-#undef WIDE_LOAD_W
-#undef WIDE_STORE_W
+#undef WIDE_LOAD_B
+#undef WIDE_LOAD_FA
+#undef WIDE_TAP_OFFSETS
+#undef WIDE_GROUP
+    WIDE_STAMP(3)
 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -440,7 +446,7 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     const int QA = M_T + 2 * halo;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > 16 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
-    size_t lds = (size_t)((QA + 2) * LDK + 2 * N_T * LDK + 2 * NS) * sizeof(float);
+    size_t lds = (size_t)((QA + 2) * LDK + 2 * NS) * sizeof(float);
     lds = std::max(lds, (size_t)(WM * 64 * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
     if (const char* pad = getenv("SPDM_WIDE_LDSPAD")) lds += (size_t)atoi(pad);      // experiment: force one workgroup per CU
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -461,8 +467,8 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
 }  // namespace
 
 bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
-    return a.split && a.taps == 9 && g.m_tile == 256 && g.n_tile == 128 && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 &&
-           a.M % a.HW == 0 && a.epi == EPI_STATS && a.row_stats == nullptr && (a.debug & ~DBG_STAMP) == 0 && a.K % CK == 0 &&
+    return a.split && a.wgt_frag != nullptr && a.taps == 9 && g.m_tile == 256 && g.n_tile == 128 && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 &&
+           a.M % a.HW == 0 && a.epi == EPI_STATS && a.row_stats == nullptr && (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && a.K % CK == 0 &&
            (256 + 2 * (a.W + 1) - 1) / a.HW + 2 <= 16 && getenv("SPDM_NO_WIDE") == nullptr;
 }
 

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace spdm {
 
@@ -37,6 +38,7 @@ struct GemmArgs {
     const float* src;  int src_ld;     // [M][src_ld], K valid channels
     const float* wgt;                  // [taps][N][K]  (k contiguous); split: per 32-k chunk [32 fp16 hi | 32 fp16 lo]
     int split;                         // 0: fp32 MFMA (exact); 1: split-fp16 MFMA (wgt in the split format)
+    const float* wgt_frag;             // optional: fragment-order copy of the split weights (frag_order_weights) -> conv_wide.hip
     float* dst;        int dst_ld;
     int M, K, N;
     int taps;                          // 1, 3 (vertical taps, W == 1) or 9
@@ -58,6 +60,27 @@ double gemm_flops(const GemmArgs& a);
 // workgroups per CU); launch_gemm routes to it when conv_wide_supported
 bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g);
 hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s);
+
+// Fragment-order copy of split-format weights [taps][N][K] for conv_wide.hip: one 1-KiB block per MFMA B operand,
+//   block ((tap K/32 + chunk) N/32 + nb) x {K=16 step s2} x {hi, lo},  lane (kh 32 + li) -> 16 bytes =
+//   8 fp16 of row nb 32 + li, k = chunk 32 + s2 16 + kh 8 ..  -- so a wave's operand load is one coalesced
+//   global_load_dwordx4.  Same bytes as the split array, permuted.  (N % 32 == 0, K % 32 == 0.)
+inline std::vector<float> frag_order_weights(const std::vector<float>& split, int taps, int N, int K) {
+    std::vector<float> out(split.size());
+    const int nch = K / 32, nbn = N / 32;
+    for (int t = 0; t < taps; ++t)
+        for (int c = 0; c < nch; ++c)
+            for (int nb = 0; nb < nbn; ++nb)
+                for (int s2 = 0; s2 < 2; ++s2)
+                    for (int part = 0; part < 2; ++part)
+                        for (int kh = 0; kh < 2; ++kh)
+                            for (int li = 0; li < 32; ++li) {
+                                const size_t dst = (((((size_t)(t * nch + c) * nbn + nb) * 2 + s2) * 2 + part) * 64 + kh * 32 + li) * 4;
+                                const size_t src = ((size_t)t * N + nb * 32 + li) * K + c * 32 + part * 16 + s2 * 8 + kh * 4;
+                                for (int j = 0; j < 4; ++j) out[dst + j] = split[src + j];
+                            }
+    return out;
+}
 
 // ---- streaming / small kernels (elementwise.hip) -------------------------------------------
 // first conv, Cin = 1, fused zero-padding of the (H0, D) trajectory to (Hp, Wp)

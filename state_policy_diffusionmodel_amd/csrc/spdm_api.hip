@@ -110,7 +110,7 @@ struct Value {             // a tensor plus the GroupNorm affine still pending o
     bool pending_gn() const { return st.valid; }
 };
 
-struct ConvW { float* w = nullptr; float* ws = nullptr; int taps = 0, cin = 0, cout = 0; };   // ws: split-fp16 copy
+struct ConvW { float* w = nullptr; float* ws = nullptr; float* wf = nullptr; int taps = 0, cin = 0, cout = 0; };   // ws: split-fp16 copy; wf: its fragment-order copy (conv_wide.hip)
 struct DoubleConvW { ConvW first, second; float* gamma = nullptr; float* beta = nullptr; };
 struct LinW { float* w = nullptr; float* ws = nullptr; float* b = nullptr; int in = 0, out = 0; };
 struct ResampleW { DoubleConvW dc1, dc2; LinW emb, film; float* temb_table = nullptr; int cout = 0; };
@@ -366,8 +366,7 @@ struct Loader {
     }
     // fp32 [rows][K] -> per 32-k chunk [32 x fp16 hi | 32 x fp16 lo] of x' = 128 x (conv_gemm.hip, PREC_SPLIT):
     // hi = fp16(x'), lo = fp16(x' - hi); same byte size as the fp32 array
-    float* upload_split(const std::vector<float>& v, size_t K) {
-        if (K % 32 != 0) { err = fail(SPDM_ERR_INVALID, "split weights need K %% 32 == 0"); return nullptr; }
+    static std::vector<float> split_format(const std::vector<float>& v) {
         std::vector<float> out(v.size());
         for (size_t base = 0; base < v.size(); base += 32) {
             _Float16* hp = reinterpret_cast<_Float16*>(&out[base]);
@@ -378,7 +377,11 @@ struct Loader {
                 hp[32 + j] = (_Float16)(x - (float)hi);
             }
         }
-        return upload(out);
+        return out;
+    }
+    float* upload_split(const std::vector<float>& v, size_t K) {
+        if (K % 32 != 0) { err = fail(SPDM_ERR_INVALID, "split weights need K %% 32 == 0"); return nullptr; }
+        return upload(split_format(v));
     }
     float* upload(const std::vector<float>& v) {
         void* p = nullptr;
@@ -404,6 +407,7 @@ struct Loader {
         }
         c.w = upload(v);
         c.ws = (cin % 32 == 0) ? upload_split(v, cin) : nullptr;
+        if (taps == 9 && cin % 32 == 0 && cout % 128 == 0) c.wf = upload(frag_order_weights(split_format(v), taps, cout, cin));
         c.taps = taps; c.cin = cin; c.cout = cout;
         return c;
     }
@@ -671,6 +675,7 @@ struct Ctx {
         GemmArgs a{};
         a.split = split;
         a.src = in.t.p; a.src_ld = in.t.C; a.wgt = a.split ? w.ws : w.w; a.dst = out.t.p; a.dst_ld = w.cout;
+        a.wgt_frag = a.split ? w.wf : nullptr;
         if (a.wgt == nullptr) { if (!err) err = fail(SPDM_ERR_STATE, "plan: conv weights missing"); return out; }
         a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
         a.H = Hl(level); a.W = Wl(level); a.HW = HW;
@@ -1088,7 +1093,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     HIP_TRY(hipSetDevice(device));
     const int HW = H * W, M = B * HW;
     const GemmGeom g = gemm_geometry(M, Cout, HW, taps, split);
-    float *src = nullptr, *wgt = nullptr, *wgt32 = nullptr, *dst = nullptr, *dst2 = nullptr, *gb = nullptr, *resid = nullptr;
+    float *src = nullptr, *wgt = nullptr, *wgt32 = nullptr, *dst = nullptr, *dst2 = nullptr, *gb = nullptr, *resid = nullptr, *wfrag = nullptr;
     double *st_in = nullptr, *st_out = nullptr;
     const size_t nsrc = (size_t)M * Cin, nw = (size_t)taps * Cout * Cin, ndst = (size_t)M * Cout;
     HIP_TRY(hipMalloc((void**)&src, nsrc * 4));
@@ -1120,6 +1125,11 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
                 }
             }
             hw.swap(out);
+            if (taps == 9 && Cout % 128 == 0 && Cin % 32 == 0) {
+                const std::vector<float> fr = frag_order_weights(hw, taps, Cout, Cin);
+                HIP_TRY(hipMalloc((void**)&wfrag, nw * 4));
+                HIP_TRY(hipMemcpy(wfrag, fr.data(), nw * 4, hipMemcpyHostToDevice));
+            }
         }
         std::vector<double> hst((size_t)B * 2);
         for (int b = 0; b < B; ++b) { hst[2 * b] = 0.0; hst[2 * b + 1] = (double)Cin * HW / 3.0; }
@@ -1130,7 +1140,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
         HIP_TRY(hipMemset(resid, 0, ndst * 4));
     }
     GemmArgs a{};
-    a.src = src; a.src_ld = Cin; a.wgt = wgt; a.split = split; a.dst = dst; a.dst_ld = Cout;
+    a.src = src; a.src_ld = Cin; a.wgt = wgt; a.wgt_frag = wfrag; a.split = split; a.dst = dst; a.dst_ld = Cout;
     a.M = M; a.K = Cin; a.N = Cout; a.taps = taps; a.H = H; a.W = W; a.HW = HW;
     a.pro = pro;
     a.pro_stats.p = st_in; a.pro_stats.slots = 1; a.pro_stats.m_tile = HW; a.pro_stats.n_tiles = 1; a.pro_stats.HW = HW;
@@ -1159,7 +1169,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     double maxdiff = -1.0;
     if (e == hipSuccess && debug == 0) {      // self-check: same data through the exact fp32-MFMA configuration
         GemmArgs b2 = a;
-        b2.split = 0; b2.wgt = wgt32; b2.dst = dst2;
+        b2.split = 0; b2.wgt = wgt32; b2.wgt_frag = nullptr; b2.dst = dst2;
         e = launch_gemm(b2, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         std::vector<float> h1(ndst), h2(ndst);
@@ -1190,7 +1200,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
         }
         (void)hipFree(d_stamps);
     }
-    (void)hipFree(wgt32); (void)hipFree(dst2);
+    (void)hipFree(wgt32); (void)hipFree(dst2); (void)hipFree(wfrag);
     (void)hipFree(src); (void)hipFree(wgt); (void)hipFree(dst); (void)hipFree(resid); (void)hipFree(gb); (void)hipFree(st_in); (void)hipFree(st_out);
     if (e != hipSuccess) return fail(SPDM_ERR_HIP, "bench_gemm: %s", hipGetErrorString(e));
     *ms_out = ms / iters;

@@ -20,7 +20,7 @@ SHAPES = {  # name: (H, W, Cin, Cout, taps, pro, epi)
     "sa6.qkv": (32, 8, 64, 192, 1, 0, 1), "sa6.out": (32, 8, 64, 64, 1, 0, 3), "sa6.ff1": (32, 8, 64, 64, 1, 0, 2),
     "sa1.qkv": (16, 4, 128, 384, 1, 0, 1),
 }
-DBG = {"full": 0, "stamp": 128, "pp": 64, "pp+stamp": 192, "noMFMA": 1, "noWload": 2, "noGELU": 4, "noStore": 8, "noAload": 16, "noMFMA+noW": 3, "noMFMA+noW+noA+noSt": 27}
+DBG = {"full": 0, "stamp": 128, "pp": 64, "pp+stamp": 192, "noMFMA": 1, "noWload": 2, "noGELU": 4, "noStore": 8, "noAload": 16, "noMFMA+noW": 3, "noW+stamp": 130, "noMFMA+noW+noA+noSt": 27}
 split = 0 if "--f32" in sys.argv else 1
 names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(SHAPES)
 for n in names:
@@ -28,7 +28,7 @@ for n in names:
     flops = 2.0 * B * H * W * Cin * Cout * taps
     out = []
     for dn, dv in DBG.items():
-        if dn in ("stamp", "pp", "pp+stamp"):
+        if dn in ("stamp", "pp", "pp+stamp", "noW+stamp"):
             if "--stamp" not in sys.argv or (dn != "stamp" and os.environ.get("SPDM_STAMP_DUMP")):
                 continue
         elif dn != "full" and "--ablate" not in sys.argv:
