@@ -670,8 +670,9 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
     g.n_tile = nt128 ? 128 : 64;
     if (!big && nt128 && (long long)((M + 127) / 128) * nt128 < 192) g.n_tile = 64;
     // 64-wide outputs: 512-row tiles keep 72 MFMAs per wave between barriers (8 waves x 64x64)
+    // (superseded for HW % 4 == 0 by conv_wide.hip's 256 x 64 configuration, two workgroups per CU)
     if (big && g.n_tile == 64 && taps == 9 && (long long)((M + 511) / 512) * (N / 64) >= 192 &&
-        getenv("SPDM_NO_T512") == nullptr)
+        getenv("SPDM_NO_T512") == nullptr && ((HW & 3) != 0 || getenv("SPDM_T512") != nullptr))
         g.m_tile = 512;
     g.n_tiles = N / g.n_tile;
     g.slots = stats_slots(HW, g.m_tile, g.n_tiles);

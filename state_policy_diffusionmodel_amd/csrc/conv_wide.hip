@@ -66,9 +66,9 @@ __device__ __forceinline__ float half_sum_dpp(float v) {
     return v;
 }
 
-template <int WM, int PRO>
-__global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS, const int stagger) {
-    constexpr int WN = 2, MT = 4, NT = 2;
+template <int NT, int PRO>
+__global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS, const int stagger) {
+    constexpr int WM = 2, WN = 2, MT = 4;               // NT = 2: 256 x 128 tile (wave 128 x 64); NT = 1: 256 x 64 (wave 128 x 32)
     constexpr int NTHR = WM * WN * 64;
     constexpr int RP = NTHR / 8;
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
@@ -327,6 +327,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
 #undef WIDE_TAP_OFFSETS
 #undef WIDE_GROUP
     WIDE_STAMP(3)
+    __syncthreads();          // the epilogue re-uses the slab's LDS: every wave must be done reading A fragments
 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -439,18 +440,18 @@ __global__ __launch_bounds__(WM * 128, 2) void conv3x3_wide_kernel(const GemmArg
 #undef WIDE_FINE
 }
 
-template <int WM, int PRO>
+template <int NT, int PRO>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
-    constexpr int M_T = WM * 128, N_T = 128, NTHR = WM * 128;
+    constexpr int M_T = 256, N_T = 64 * NT, NTHR = 256;
     const int halo = a.W + 1;
     const int QA = M_T + 2 * halo;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > 16 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     size_t lds = (size_t)((QA + 2) * LDK + 2 * NS) * sizeof(float);
-    lds = std::max(lds, (size_t)(WM * 64 * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
+    lds = std::max(lds, (size_t)(128 * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
     if (const char* pad = getenv("SPDM_WIDE_LDSPAD")) lds += (size_t)atoi(pad);      // experiment: force one workgroup per CU
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<WM, PRO>;
+    auto kern = conv3x3_wide_kernel<NT, PRO>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -467,16 +468,21 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
 }  // namespace
 
 bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
-    return a.split && a.wgt_frag != nullptr && a.taps == 9 && g.m_tile == 256 && g.n_tile == 128 && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 &&
+    return a.split && a.wgt_frag != nullptr && a.taps == 9 && g.m_tile == 256 && (g.n_tile == 128 || g.n_tile == 64) && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 &&
            a.M % a.HW == 0 && a.epi == EPI_STATS && a.row_stats == nullptr && (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && a.K % CK == 0 &&
            (256 + 2 * (a.W + 1) - 1) / a.HW + 2 <= 16 && getenv("SPDM_NO_WIDE") == nullptr;
 }
 
 hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     if (!conv_wide_supported(a, g)) return hipErrorInvalidValue;
-    if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE>(a, g, s);
-    if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN>(a, g, s);
-    return launch_wide_cfg<2, PRO_GN_GELU>(a, g, s);
+    if (g.n_tile == 128) {
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE>(a, g, s);
+        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN_GELU>(a, g, s);
+    }
+    if (a.pro == PRO_NONE) return launch_wide_cfg<1, PRO_NONE>(a, g, s);
+    if (a.pro == PRO_GN) return launch_wide_cfg<1, PRO_GN>(a, g, s);
+    return launch_wide_cfg<1, PRO_GN_GELU>(a, g, s);
 }
 
 }  // namespace spdm
