@@ -66,14 +66,14 @@ __device__ __forceinline__ float half_sum_dpp(float v) {
     return v;
 }
 
-template <int NT, int PRO>
+template <int NT, int PRO, bool W2>
 __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS, const int stagger) {
     constexpr int WM = 2, WN = 2, MT = 4;               // NT = 2: 256 x 128 tile (wave 128 x 64); NT = 1: 256 x 64 (wave 128 x 32)
     constexpr int NTHR = WM * WN * 64;
     constexpr int RP = NTHR / 8;
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
     constexpr int APASS = (M_T + 18 + RP - 1) / RP;
-    static_assert(APASS <= 16, "sample-index packing");
+    static_assert(APASS <= 12, "sample-index packing: 5 bits per pass in 64");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
         const bool v = (q < QA) && (m >= 0) && (m < M);
         if (v) {
             avalid |= 1u << p;
-            if (pro) abidx |= (unsigned long long)(m / HW - bh_first) << (4 * p);
+            if (pro) abidx |= (unsigned long long)(m / HW - bh_first) << (5 * p);
         }
     }
     const float* abase = a.src + c4 * 4;
@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     const int koff = kh * 4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int r = wm * MT * 32 + mt * 32 + li;
+        // W2 (image width 2): the wave's rows are permuted so that even tiles hold the w = 0 positions and odd tiles
+        // the w = 1 positions; a side column of the kernel then only concerns the tiles of one parity (below)
+        const int r = W2 ? wm * MT * 32 + (mt >> 1) * 64 + 2 * li + (mt & 1) : wm * MT * 32 + mt * 32 + li;
         aoff[mt] = (r + halo) * LDK + koff;
         unsigned mask = 0u;
         const int m = m0 + r;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                      \
             f32x4 v_ = areg[p_];                                                                     \
             if (pro) {                                                                               \
-                const int bi_ = (int)((abidx >> (4 * p_)) & 15ull);                                  \
+                const int bi_ = (int)((abidx >> (5 * p_)) & 31ull);                                  \
                 const float rs_ = srstd[bi_], mu_ = smean[bi_];                                      \
                 v_.x = (v_.x - mu_) * (rs_ * g4r.x) + b4r.x;                                         \
                 v_.y = (v_.y - mu_) * (rs_ * g4r.y) + b4r.y;                                         \
@@ -265,9 +267,76 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
         }                                                                                            \
     }
 
+    f16x8 fa[2][2], fb[2][NT][2];
+    if constexpr (W2) {
+        // Image width 2: for w = 0 the dw = -1 column of the kernel only sees zero padding, for w = 1 the dw = +1
+        // column.  With the rows permuted by parity (above), a kernel row costs: the centre tap on all four tiles,
+        // the dw = +1 tap on the even tiles, the dw = -1 tap on the odd tiles -- 16 tile steps instead of 24, only
+        // all-zero products dropped.  Loop body = one kernel row = six K=16 half-taps (centre, +1, -1) x (s2 0, 1).
+        const int nrows = nchunks * 3;
+        int aoc[MT], aos[MT];
+#define W2_ROW_OFFSETS(kr_)                                                                          \
+        {                                                                                            \
+            const int sh_ = ((kr_) - 1) * W * LDK;                                                   \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) {                                  \
+                aoc[mt_] = ((amask[mt_] >> ((kr_) * 3 + 1)) & 1u) ? aoff[mt_] + sh_ : zoff;          \
+                const int ts_ = (mt_ & 1) ? (kr_) * 3 : (kr_) * 3 + 2;                               \
+                aos[mt_] = ((amask[mt_] >> ts_) & 1u) ? aoff[mt_] + sh_ + ((mt_ & 1) ? -LDK : LDK) : zoff; \
+            }                                                                                        \
+        }
+        WIDE_LOAD_B(0, 0, 1, 0)
+        WIDE_LOAD_A(0)
+        WIDE_STAGE_A()
+        __syncthreads();
+        WIDE_STAMP(2)
+        W2_ROW_OFFSETS(0)
+        WIDE_LOAD_FA(0, aoc[0], 0)
+        int chunk = 0, kr = 0;
+        for (int r = 0; r < nrows; ++r) {
+            int nkr = kr + 1, nchunk = chunk;
+            if (nkr == 3) { nkr = 0; nchunk = chunk + 1; }
+            const bool have_next = (r + 1 < nrows);
+            const bool next_A = have_next && (nkr == 0);
+            const int bkr = have_next ? nkr : kr, bchunk = have_next ? nchunk : chunk;   // B prefetch past this row (last row: re-read)
+            const int tc = kr * 3 + 1, tp = kr * 3 + 2, tm = kr * 3;
+            W2_ROW_OFFSETS(kr)
+            const int aoc_n0 = ((amask[0] >> (nkr * 3 + 1)) & 1u) ? aoff[0] + (nkr - 1) * W * LDK : zoff;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = q < 8 ? q / 4 : 2 + (q - 8) / 2;                          // half-tap 0..5
+                const int mt = q < 8 ? q % 4 : (k < 4 ? 0 : 1) + 2 * ((q - 8) % 2);     // tile of this step
+                if (q == 0) { WIDE_LOAD_B(1, chunk, tc, 1) }
+                if (q == 4) { WIDE_LOAD_B(0, chunk, tp, 0) }
+                if (q == 8) { WIDE_LOAD_B(1, chunk, tp, 1) }
+                if (q == 10) { WIDE_LOAD_B(0, chunk, tm, 0) }
+                if (q == 12) { WIDE_LOAD_B(1, chunk, tm, 1) }
+                if (q == 14) { WIDE_LOAD_B(0, bchunk, bkr * 3 + 1, 0) }
+                if (q + 1 < 16) {
+                    const int qn = q + 1;
+                    const int kn = qn < 8 ? qn / 4 : 2 + (qn - 8) / 2;
+                    const int mtn = qn < 8 ? qn % 4 : (kn < 4 ? 0 : 1) + 2 * ((qn - 8) % 2);
+                    WIDE_LOAD_FA(qn & 1, (kn < 2 ? aoc[mtn] : aos[mtn]), kn & 1)
+                } else if (have_next && !next_A) {
+                    WIDE_LOAD_FA(0, aoc_n0, 0)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                WIDE_GROUP(q & 1, k & 1, mt)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (next_A) {
+                WIDE_LOAD_A(nchunk)
+                __syncthreads();
+                WIDE_STAGE_A()
+                __syncthreads();
+                WIDE_LOAD_FA(0, aoc_n0, 0)
+            }
+            kr = nkr;
+            chunk = nchunk;
+        }
+#undef W2_ROW_OFFSETS
+    } else {
     const int niter = nchunks * 9;
 
-    f16x8 fa[2][2], fb[2][NT][2];
     int ao[MT], aon[MT];
     WIDE_LOAD_B(0, 0, 0, 0)
     WIDE_LOAD_A(0)
@@ -320,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
         tap = ntap;
         chunk = nchunk;
     }
+    }
 #undef WIDE_LOAD_A
 #undef WIDE_STAGE_A
 #undef WIDE_LOAD_B
@@ -345,7 +415,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int r0 = wm * MT * 32 + mt * 32 + 8 * g + 4 * kh;
+            // 4-row unit of this register quad (W2: the quad's rows are 2 apart inside one 8-row block -> slot unit
+            // 2 (block) + parity; a sample is still a contiguous run of HW / 4 slot units because HW % 8 == 0)
+            const int r0 = W2 ? 4 * (wm * 32 + (mt >> 1) * 16 + 4 * g + 2 * kh + (mt & 1)) : wm * MT * 32 + mt * 32 + 8 * g + 4 * kh;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -373,7 +445,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
                 const int col_l = wn * NT * 32 + nt * 32 + li;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row_l = wm * 64 + mq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int ri = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int row_l = W2 ? wm * 64 + 2 * ri + mq : wm * 64 + mq * 32 + ri;
                     otile[row_l * N_T + col_l] = acc[2 * h + mq][nt][r];
                 }
             }
@@ -440,18 +513,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 #undef WIDE_FINE
 }
 
-template <int NT, int PRO>
+template <int NT, int PRO, bool W2 = false>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = 256, N_T = 64 * NT, NTHR = 256;
     const int halo = a.W + 1;
     const int QA = M_T + 2 * halo;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
-    if (NS > 16 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
+    if (NS > 32 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     size_t lds = (size_t)((QA + 2) * LDK + 2 * NS) * sizeof(float);
     lds = std::max(lds, (size_t)(128 * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
     if (const char* pad = getenv("SPDM_WIDE_LDSPAD")) lds += (size_t)atoi(pad);      // experiment: force one workgroup per CU
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<NT, PRO>;
+    auto kern = conv3x3_wide_kernel<NT, PRO, W2>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -467,14 +540,26 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
 
 }  // namespace
 
+static bool wide_w2(const GemmArgs& a) { return a.W == 2 && getenv("SPDM_NO_W2") == nullptr; }
+
 bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
-    return a.split && a.wgt_frag != nullptr && a.taps == 9 && g.m_tile == 256 && (g.n_tile == 128 || g.n_tile == 64) && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 &&
-           a.M % a.HW == 0 && a.epi == EPI_STATS && a.row_stats == nullptr && (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && a.K % CK == 0 &&
-           (256 + 2 * (a.W + 1) - 1) / a.HW + 2 <= 16 && getenv("SPDM_NO_WIDE") == nullptr;
+    const bool ok = a.split && a.wgt_frag != nullptr && a.taps == 9 && g.m_tile == 256 && (g.n_tile == 128 || g.n_tile == 64) &&
+                    a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 && a.M % a.HW == 0 && a.epi == EPI_STATS && a.row_stats == nullptr &&
+                    (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && a.K % CK == 0 &&
+                    (256 + 2 * (a.W + 1) - 1) / a.HW + 2 <= 32 && getenv("SPDM_NO_WIDE") == nullptr;
+    if (!ok) return false;
+    // width-2 maps: only with the zero-tap skipping variant (otherwise conv_gemm.hip's W2 configuration does less work)
+    if (wide_w2(a)) return g.n_tile == 128 && (a.HW & 7) == 0;
+    return true;
 }
 
 hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     if (!conv_wide_supported(a, g)) return hipErrorInvalidValue;
+    if (wide_w2(a)) {
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, true>(a, g, s);
+        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, true>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN_GELU, true>(a, g, s);
+    }
     if (g.n_tile == 128) {
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN>(a, g, s);

@@ -15,7 +15,8 @@ SHAPES = {  # name: (H, W, Cin, Cout, taps, pro, epi)
     "up3.dc1a": (32, 8, 128, 128, 9, 0, 0), "up3.dc1b": (32, 8, 128, 128, 9, 2, 0),
     "up3.dc2a": (32, 8, 128, 64, 9, 1, 0), "up3.dc2b": (32, 8, 64, 64, 9, 2, 0),
     "inc.b": (32, 8, 64, 64, 9, 2, 0), "up2.dc2a": (16, 4, 256, 64, 9, 1, 0),
-    "up2.dc1a": (16, 4, 256, 256, 9, 0, 0), "up1.dc1a": (8, 2, 512, 512, 9, 0, 0),
+    "up2.dc1a": (16, 4, 256, 256, 9, 0, 0), "up1.dc1a": (8, 2, 512, 512, 9, 0, 0), "up1.dc1b": (8, 2, 512, 512, 9, 2, 0),
+    "up1.dc2a": (8, 2, 512, 128, 9, 1, 0), "down2.b": (8, 2, 128, 128, 9, 2, 0), "down2.c": (8, 2, 128, 256, 9, 1, 0),
     "bot2a": (4, 1, 512, 512, 3, 1, 0), "down3": (4, 1, 256, 256, 3, 2, 0),
     "sa6.qkv": (32, 8, 64, 192, 1, 0, 1), "sa6.out": (32, 8, 64, 64, 1, 0, 3), "sa6.ff1": (32, 8, 64, 64, 1, 0, 2),
     "sa1.qkv": (16, 4, 128, 384, 1, 0, 1),

@@ -14,7 +14,7 @@ agg = {}
 for r in step:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += d
-    n = r["Kernel_Name"].replace("spdm::", "").replace("void ", "").split("(")[0][:46]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("spdm::", "").replace("void ", "").split("(")[0][:46]
     agg[n] = agg.get(n, 0.0) + d
     if "-v" in sys.argv:
         print(f"{n:48s} grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):7d} vgpr={r['VGPR_Count']:>4s}+{r['Accum_VGPR_Count']:>3s} {d:9.1f} us")
