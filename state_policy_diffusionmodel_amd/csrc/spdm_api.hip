@@ -164,6 +164,20 @@ struct spdm_handle {
     // debug
     std::map<std::string, Tensor> taps;
     int tapB = 0;
+    // hipGraph of one denoise step (advance -> U-Net -> scheduler update), replayed by spdm_sample_run
+    struct StepGraphKey {
+        int B = 0, inp_h = 0, per_sample = 0, have_film = 0, sched_kind = 0, n_steps = 0;
+        const void *inpaint = nullptr, *noise = nullptr, *history = nullptr;
+        unsigned long long seed = 0, offset = 0;
+        bool operator==(const StepGraphKey& o) const {
+            return B == o.B && inp_h == o.inp_h && per_sample == o.per_sample && have_film == o.have_film &&
+                   sched_kind == o.sched_kind && n_steps == o.n_steps && inpaint == o.inpaint && noise == o.noise &&
+                   history == o.history && seed == o.seed && offset == o.offset;
+        }
+    } graph_key;
+    hipGraph_t step_graph = nullptr;
+    hipGraphExec_t step_exec = nullptr;
+    hipStream_t gstream = nullptr;        // blocking stream the loop runs on when the caller passes the NULL stream
     // profiling of the dominant kernel class
     bool prof = false;
     std::vector<ProfEvt> prof_evts;
@@ -333,6 +347,9 @@ extern "C" void spdm_destroy(spdm_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
+    if (h->step_exec) (void)hipGraphExecDestroy(h->step_exec);
+    if (h->step_graph) (void)hipGraphDestroy(h->step_graph);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
     for (void* p : h->owned) (void)hipFree(p);
     for (auto& e : h->prof_evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete h;
@@ -989,23 +1006,78 @@ extern "C" int spdm_sample_begin(spdm_handle* h, int32_t B, const float* d_cond,
     return SPDM_OK;
 }
 
+// one denoise iteration on stream s: loop bookkeeping (explicit index i >= 0, or "advance by one" for i < 0 --
+// the form a captured graph replays), U-Net, fused 1x1 conv + scheduler update + inpainting
+static int enqueue_step(spdm_handle* h, int i, hipStream_t s) {
+    if (i >= 0) HIP_TRY(launch_set_step(h->d_step, h->d_t, h->d_timesteps, h->n_steps, i, s));
+    else HIP_TRY(launch_advance(h->d_step, h->d_t, h->d_timesteps, h->n_steps, s));
+    Ctx c{h, h->sB, s, false};
+    c.h_tcount = 1;
+    h->arena.reset();
+    Tensor feat;
+    SPDM_TRY(plan_unet(c, h->d_x, h->have_film, &feat));
+    StepArgs a = step_args(h, h->sB, feat);
+    HIP_TRY(launch_out_step(a, s));
+    return SPDM_OK;
+}
+
+// Capture one step into a hipGraph (the step's ~70 launches take the same arguments in every iteration: the loop
+// counter, the timestep and the noise offset live on the device).  Returns false -- with the stream usable and no
+// error state left behind -- when the runtime refuses; the caller then stays on plain launches.
+static bool build_step_graph(spdm_handle* h, hipStream_t s) {
+    if (h->step_exec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(h->step_exec); h->step_exec = nullptr; }
+    if (h->step_graph) { (void)hipGraphDestroy(h->step_graph); h->step_graph = nullptr; }
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const int rc = enqueue_step(h, -1, s);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != SPDM_OK || e != hipSuccess || g == nullptr) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return false;
+    }
+    hipGraphExec_t ge = nullptr;
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess || ge == nullptr) {
+        (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return false;
+    }
+    h->step_graph = g;
+    h->step_exec = ge;
+    return true;
+}
+
 extern "C" int spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_end, void* stream) {
     if (!h || !h->session) return fail(SPDM_ERR_STATE, "spdm_sample_begin has not been called");
     if (step_begin < 0 || step_end > h->n_steps || step_begin > step_end)
         return fail(SPDM_ERR_INVALID, "step range [%d,%d) outside [0,%d]", step_begin, step_end, h->n_steps);
     HIP_TRY(hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    const int B = h->sB;
-    for (int i = step_begin; i < step_end; ++i) {
-        HIP_TRY(launch_set_step(h->d_step, h->d_t, h->d_timesteps, h->n_steps, i, s));
-        Ctx c{h, B, s, false};
-        c.h_tcount = 1;
-        h->arena.reset();
-        Tensor feat;
-        SPDM_TRY(plan_unet(c, h->d_x, h->have_film, &feat));
-        StepArgs a = step_args(h, B, feat);
-        HIP_TRY(launch_out_step(a, s));
+    // Graph replay (default; SPDM_NO_GRAPH=1 disables): not while the per-launch profiler or the debug taps are on.
+    const bool graphs_on = getenv("SPDM_NO_GRAPH") == nullptr;
+    bool use_graph = graphs_on && !h->prof && !h->arena.keep && step_end - step_begin >= 3;
+    if (use_graph && s == nullptr) {
+        // the legacy NULL stream cannot be captured: run on a blocking stream of our own (implicitly ordered with
+        // NULL-stream work on both sides) and keep the contract "NULL stream => complete on return"
+        if (!h->gstream && hipStreamCreate(&h->gstream) != hipSuccess) { (void)hipGetLastError(); h->gstream = nullptr; use_graph = false; }
+        if (use_graph) s = h->gstream;
     }
+    int i = step_begin;
+    if (use_graph) {
+        SPDM_TRY(enqueue_step(h, i, s));         // first step: explicit index; also makes sure every kernel has been launched once
+        ++i;
+        spdm_handle::StepGraphKey key;
+        key.B = h->sB; key.inp_h = h->s_inp_h; key.per_sample = h->s_inp_per_sample; key.have_film = h->have_film ? 1 : 0;
+        key.sched_kind = h->sched_kind; key.n_steps = h->n_steps; key.inpaint = h->s_inpaint; key.noise = h->s_noise;
+        key.history = h->s_history; key.seed = h->s_seed; key.offset = h->s_offset;
+        if (!(h->step_exec && key == h->graph_key)) {
+            if (build_step_graph(h, s)) h->graph_key = key;
+            else use_graph = false;
+        }
+        if (use_graph)
+            for (; i < step_end; ++i) HIP_TRY(hipGraphLaunch(h->step_exec, s));
+    }
+    for (; i < step_end; ++i) SPDM_TRY(enqueue_step(h, i, s));
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return SPDM_OK;
 }

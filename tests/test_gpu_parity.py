@@ -278,6 +278,40 @@ def test_full_size_batch_properties():
         eng.close()
 
 
+def test_graph_replay_equals_plain_launches(monkeypatch):
+    """spdm_sample_run replays each denoise step as a hipGraph; the trajectory (every iterate) must be bit-identical
+    to the plain-launch loop, for both schedulers, and a changed session (new seed) must rebuild the graph."""
+    from state_policy_diffusionmodel_amd.schedulers import DDIMScheduler, DDPMScheduler
+    H, D, B, T = 16, 3, 3, 12
+    cond_dim = 1350
+    sd = random_state_dict(cond_dim, seed=5, attention=True)
+    g = torch.Generator().manual_seed(11)
+    cond = torch.randn(B, 1, 10, 135, generator=g).cuda()
+    x_T = torch.rand(B, 1, H, D, generator=g).cuda()
+    inpaint = (torch.rand(B, 1, 1, D, generator=g) * 2 - 1).cuda()
+    for kind in (DDPMScheduler, DDIMScheduler):
+        eng = make_engine(H, D, cond_dim, B, sd, T=T)
+        sched = kind(num_train_timesteps=T)
+        sched.set_timesteps(T)
+        eng.set_scheduler(sched)
+        res = {}
+        for mode in ("graph", "plain"):
+            if mode == "plain":
+                monkeypatch.setenv("SPDM_NO_GRAPH", "1")
+            else:
+                monkeypatch.delenv("SPDM_NO_GRAPH", raising=False)
+            for seed in (3, 4):      # device Philox noise: the seed is baked into the step's arguments
+                x0, hist = eng.sample(cond, x_T, noise=None, inpaint=inpaint, seed=seed, history=True)
+                res[(mode, seed)] = (x0.cpu(), hist.cpu())
+        for seed in (3, 4):
+            assert torch.equal(res[("graph", seed)][0], res[("plain", seed)][0])
+            assert torch.equal(res[("graph", seed)][1], res[("plain", seed)][1])
+        if kind is DDPMScheduler:
+            assert not torch.equal(res[("graph", 3)][0], res[("graph", 4)][0])
+        eng.close()
+    monkeypatch.delenv("SPDM_NO_GRAPH", raising=False)
+
+
 def test_error_behaviour():
     B, H, D, cd = 2, 16, 3, 14
     sd = weights(cd, 5)
