@@ -1,29 +1,33 @@
-// conv_wide.hip -- 3x3 convolution as an implicit GEMM, the configuration for the LARGE layers
-// (128-wide output tiles at levels 0 and 1: up3.dc1, up2.dc1, down1 -- 55 % of the path's FLOPs).
+// conv_wide.hip -- 3x3 convolution as an implicit GEMM: the kernel for every 3x3 layer of levels 0-2 at large
+// batch (256-row output tiles; 80 % of the path's FLOPs).
 //
-// Same math, operand formats and LDS slab layout as conv_gemm.hip (split-fp16 operands, three
-// v_mfma_f32_32x32x16_f16 per K = 16 into one fp32 accumulator, halo'd input slab with the
-// GroupNorm(1,C) -> GELU prologue applied at staging, GroupNorm partial sums as the epilogue;
-// replaces nn.Conv2d(k=3, padding=1, bias=False) + the GroupNorm/GELU around it,
-// models/Unet_FiLmLayer.py:101-115).  What differs is how the work is laid on the CU:
+// Same math, operand formats and LDS slab layout as conv_gemm.hip (split-fp16 operands, hi*hi + hi*lo + lo*hi into
+// one fp32 accumulator, halo'd input slab with the GroupNorm(1,C) -> GELU prologue applied at staging, GroupNorm
+// partial sums as the epilogue; replaces nn.Conv2d(k=3, padding=1, bias=False) + the GroupNorm/GELU around it,
+// models/Unet_FiLmLayer.py:101-115).  What differs is how the work is laid on the CU -- each point below answers a
+// measurement of the first kernel (PMC counters and in-kernel s_memtime timelines):
 //
-//   * one workgroup = 4 waves (one per SIMD), each owning a 128 x 64 accumulator tile
-//     (8 MFMA tiles = 128 accumulator registers): 256 x 128 outputs per workgroup with HALF the
-//     weight-fragment LDS reads per MFMA of the 8-wave 64 x 64-per-wave configuration;
-//   * the workgroup needs 77 KiB of LDS and <= 256 registers, so TWO workgroups share a CU and run
-//     out of phase: one workgroup's prologue, slab hand-over, barrier waits and store tail overlap
-//     the other's MFMA blocks (the 8-wave configuration runs one workgroup per CU, all of whose
-//     waves stall together: measured 44-50 % matrix-pipe occupancy);
+//   * v_mfma_f32_16x16x32_f16 instead of 32x32x16: same cycles per FLOP, but this path is clock-throttled by its own
+//     MFMA load and the 16x16x32 shape holds a ~10 % higher clock on live data (measured in place: -9..-18 % time);
+//     one instruction covers the whole 32-channel chunk of a tap;
+//   * one workgroup = 4 waves (one per SIMD), each owning a 128 x 64 (NT = 2) or 128 x 32 (NT = 1) accumulator
+//     strip (8 x 4 or 8 x 2 tiles of 16 x 16 = 128 / 64 accumulator registers); <= 256 registers and <= 77 KiB of
+//     LDS, so two workgroups share a CU;
 //   * the WEIGHT fragments never touch LDS: the host stores a fragment-order copy of the split weights
-//     (frag_order_weights, kernels.h: one 1-KiB block per MFMA B operand, lane-contiguous), and each wave
-//     loads its B operands straight into registers with coalesced global_load_dwordx4, one K = 16
-//     half-tap (24 MFMAs) ahead; the waves of a workgroup then only meet at the slab hand-over (one
-//     barrier pair per 32-channel chunk = per 432 MFMAs, instead of one barrier per tap), and the MFMA
-//     stream of a chunk is unbroken;
-//   * the input slab for the next 32-channel chunk is loaded at the hand-over (the fragment
-//     registers are dead there) instead of being carried in registers across an MFMA block;
-//   * A fragments are software-pipelined per 6-MFMA group across taps (2 x 2 register sets);
-//   * the epilogue goes through LDS in two 128-row halves.
+//     (frag_order_weights, kernels.h: one 1-KiB block per MFMA B operand, lane-contiguous) and each wave loads its B
+//     operands straight into registers with coalesced global_load_dwordx4, one phase (48 MFMAs) ahead.  The waves of
+//     a workgroup then only meet at the slab hand-over -- one barrier pair per 32-channel chunk instead of one
+//     barrier per tap -- and the MFMA stream of a chunk is unbroken;
+//   * a "phase" is (tap, pair of 16-column tiles): 8 row tiles x 2 column tiles x 3 MFMAs.  A fragments live in a
+//     ring of three (four for W2) row tiles, read two tile steps ahead of use, across taps; B fragments in a ring of
+//     two (NT = 2) or three (NT = 1) phases.  The loop body is one kernel ROW, so every ring slot is a compile-time
+//     register set;
+//   * every load in the MFMA loop is unconditional (clamped addresses, a dump row in LDS): a branch around a load
+//     makes hipcc's waitcnt pass repeat the wait as vmcnt(0) at the next use, i.e. behind the weight loads;
+//   * width-2 maps (W2): rows are permuted by parity so that even row tiles hold w = 0 and odd ones w = 1 positions;
+//     a side column of the kernel then only concerns the tiles of one parity (32 instead of 48 tile steps per row);
+//   * epilogue: 16-lane reductions by DPP adds, per-sample fp64 totals by a one-wave butterfly, tile through LDS in
+//     two 128-row halves so that every lane stores 16 bytes.
 #include <algorithm>
 #include <cstdlib>
 
@@ -52,33 +56,36 @@ __device__ __forceinline__ f32x2 split2(float a, float b) {
     return f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 
-// Sum over the 32 lanes of a half-wave with DPP adds only (no LDS crossbar): quad swaps, row half-mirror,
-// row mirror, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3.  The total is valid in lanes 16-31 and 48-63.
-__device__ __forceinline__ float half_sum_dpp(float v) {
-#define DPP_ADD(ctrl_, rmask_)                                                                                  \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, rmask_, 0xf, false));
-    DPP_ADD(0xB1, 0xf)      // quad_perm [1,0,3,2]
-    DPP_ADD(0x4E, 0xf)      // quad_perm [2,3,0,1]
-    DPP_ADD(0x141, 0xf)     // row_half_mirror
-    DPP_ADD(0x140, 0xf)     // row_mirror
-    DPP_ADD(0x142, 0xa)     // row_bcast:15 into rows 1 and 3
+// Sum over the 16 lanes of a DPP row (quad swaps, half-mirror, mirror): every lane ends with the row total.
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+#define DPP_ADD(ctrl_)                                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, false));
+    DPP_ADD(0xB1)       // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E)       // quad_perm [2,3,0,1]
+    DPP_ADD(0x141)      // row_half_mirror
+    DPP_ADD(0x140)      // row_mirror
 #undef DPP_ADD
     return v;
 }
 
 template <int NT, int PRO, bool W2>
 __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS, const int stagger) {
-    constexpr int WM = 2, WN = 2, MT = 4;               // NT = 2: 256 x 128 tile (wave 128 x 64); NT = 1: 256 x 64 (wave 128 x 32)
-    constexpr int NTHR = WM * WN * 64;
+    constexpr int WM = 2, WN = 2;
+    constexpr int RT = 8, CT = 2 * NT;                  // 16-row / 16-column tiles of a wave's 128 x (32 NT) strip
+    constexpr int NTHR = 256;
     constexpr int RP = NTHR / 8;
-    constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
+    constexpr int M_T = 256, N_T = WN * NT * 32;
     constexpr int APASS = (M_T + 18 + RP - 1) / RP;
+    constexpr int FAR = W2 ? 4 : 3;                     // A-fragment ring (row tiles)
+    constexpr int FBR = (NT == 2) ? 2 : 3;              // B-fragment ring (phases)
+    constexpr int PH = 3 * NT;                          // phases per kernel row (generic layout)
     static_assert(APASS <= 12, "sample-index packing: 5 bits per pass in 64");
+    static_assert(!W2 || NT == 2, "the width-2 variant exists for 128-wide tiles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN, li = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN, l16 = lane & 15, kg = lane >> 4;
     const int HW = a.HW, W = a.W, H = a.H, M = a.M, K = a.K, N = a.N;
     const int halo = W + 1;
     const int QA = M_T + 2 * halo;
@@ -105,21 +112,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
         a.stamps[(size_t)bid * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);   // HW_ID
         a.stamps[(size_t)bid * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);   // XCC_ID
     }
-    const bool fine = (a.debug & DBG_STAMP) && a.stamps != nullptr && tid == 0 && bid == 700;
-    int nfine = 0;
-#define WIDE_FINE() if (fine && nfine < 120) a.stamps[(size_t)40000 * 8 + nfine++] = (unsigned long long)__builtin_amdgcn_s_memtime();
     const bool dbg_no_mfma = (a.debug & DBG_NO_MFMA) != 0, dbg_no_wload = (a.debug & DBG_NO_WLOAD) != 0;
 #else
 #define WIDE_STAMP(k_)
-#define WIDE_FINE()
     constexpr bool dbg_no_mfma = false, dbg_no_wload = false;     // ablation knobs exist in diagnostic builds only
 #endif
     WIDE_STAMP(1)
-    // Two workgroups share a CU.  Dispatched together, they would run in lock-step -- both in their MFMA loops,
-    // then both in their store tails with the matrix pipe idle.  The workgroup that landed in the CU's second
-    // wave slot therefore starts `stagger` cycles late, once (first generation only); from then on one
-    // workgroup's prologue / store tail overlaps the other's MFMA loop.  Purely a scheduling hint: results do
-    // not depend on it.
+    // experiment knob (SPDM_WIDE_STAGGER, default 0; measured: no effect): start the workgroup in the CU's second
+    // wave slot late, once
     if (stagger > 0 && bid < 2 * 256 && (__builtin_amdgcn_s_getreg(63492) & 1u)) {
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(64);
@@ -159,18 +159,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     }
     const float* abase = a.src + c4 * 4;
 
-    // ---- per-lane fragment rows and tap masks ----
-    int aoff[MT];
-    unsigned amask[MT];
-    const int koff = kh * 4;
+    // ---- A operand of row tile rt: lane (l16, kg) reads 16 bytes (8 fp16 of k = 8 kg ..) of slab row
+    //      halo + wm 128 + ROWOFF(rt) + rowlane.  W2: rows permuted by parity (even tiles w = 0, odd tiles w = 1).
+    //      The 9 tap-validity bits of each of the 8 tiles are packed three tiles to a register. ----
+#define WIDE_ROWOFF(rt_) (W2 ? (((rt_) >> 1) * 32 + ((rt_) & 1)) : (rt_) * 16)
+    const int rowlane = W2 ? 2 * l16 : l16;
+    const int aoff0 = (wm * 128 + rowlane + halo) * LDK + kg * 4;
+    const int zoff = QA * LDK + kg * 4;
+    unsigned am[3] = {0u, 0u, 0u};
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        // W2 (image width 2): the wave's rows are permuted so that even tiles hold the w = 0 positions and odd tiles
-        // the w = 1 positions; a side column of the kernel then only concerns the tiles of one parity (below)
-        const int r = W2 ? wm * MT * 32 + (mt >> 1) * 64 + 2 * li + (mt & 1) : wm * MT * 32 + mt * 32 + li;
-        aoff[mt] = (r + halo) * LDK + koff;
+    for (int rt = 0; rt < RT; ++rt) {
+        const int m = m0 + wm * 128 + WIDE_ROWOFF(rt) + rowlane;
         unsigned mask = 0u;
-        const int m = m0 + r;
         if (m < M) {
             const int p = m % HW;
             const int h = p / W, w = p - h * W;
@@ -181,21 +181,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
                 mask |= (ok ? 1u : 0u) << t;
             }
         }
-        amask[mt] = mask;
+        am[rt / 3] |= mask << (9 * (rt % 3));
     }
-    const int zoff = QA * LDK + koff;
-    // B operands: fragment-order weights, block ((tap nchunks + chunk) N/32 + nb) x {s2} x {hi, lo} of 256 floats
+    // B operand: fragment-order weights, block ((tap nchunks + chunk) N/16 + nb16) x {hi, lo} of 256 floats
     const int nchunks = K / CK;
-    const float* wfl = a.wgt_frag + lane * 4;
-    const int nb0 = (n0 >> 5) + wn * NT;
+    const float* wfl = a.wgt_frag + ((size_t)((n0 >> 4) + wn * CT) * 2) * 256 + lane * 4;
+    const size_t wtap = (size_t)(N >> 4) * 2 * 256;          // floats per (tap, chunk)
 
-    f32x16 acc[MT][NT];
+    f32x4 acc[RT][CT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 areg[APASS];
     f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};
@@ -229,8 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
             }                                                                                        \
             if (!((avalid >> p_) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                              \
             const f32x2 p0_ = split2(v_.x, v_.y), p1_ = split2(v_.z, v_.w);                          \
-            {   /* rows past the slab go to a dump row: no branch, so no conditional vmcnt wait that the   \
-                   compiler would have to repeat (as vmcnt(0), behind the W loads) at the loop head */      \
+            {   /* rows past the slab go to a dump row: no branch (see the header) */                 \
                 float* row_ = Abuf + min(p_ * RP + srow_t, QA + 1) * LDK;                            \
                 *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{p0_.x, p1_.x};       /* hi */       \
                 *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{p0_.y, p1_.y};  /* lo */       \
@@ -238,59 +234,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
             if (pro) __builtin_amdgcn_sched_barrier(0);        /* one pass at a time: register pressure */ \
         }                                                                                            \
     }
-#define WIDE_LOAD_B(set_, chunk_, tap_, s2_)                                                          \
+    // B ring slot <- the two 16-column tiles (cp_ 2, cp_ 2 + 1) of tap tap_ in chunk chunk_
+#define WIDE_LOAD_B(slot_, chunk_, tap_, cp_)                                                        \
     if (!dbg_no_wload) {                                                                             \
-        const float* p_ = wfl + ((size_t)(((tap_) * nchunks + (chunk_)) * (N >> 5) + nb0) * 4 + (s2_) * 2) * 256; \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < NT; ++nt_) {                                      \
-            fb[set_][nt_][0] = *reinterpret_cast<const f16x8*>(p_ + nt_ * 1024);                     \
-            fb[set_][nt_][1] = *reinterpret_cast<const f16x8*>(p_ + nt_ * 1024 + 256);               \
+        const float* p_ = wfl + (size_t)((tap_) * nchunks + (chunk_)) * wtap + (cp_) * 1024;         \
+        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                          \
+            fb[slot_][c_][0] = *reinterpret_cast<const f16x8*>(p_ + c_ * 512);                       \
+            fb[slot_][c_][1] = *reinterpret_cast<const f16x8*>(p_ + c_ * 512 + 256);                 \
         }                                                                                            \
     }
-#define WIDE_LOAD_FA(set_, ao_, s2_)                                                                 \
+    // A ring slot <- row tile rt_ seen through tap tap_ (slab row shift shift_ floats)
+#define WIDE_LOAD_FA(slot_, tap_, shift_, rt_)                                                       \
     {                                                                                                \
-        fa[set_][0] = *reinterpret_cast<const f16x8*>(Abuf + (ao_) + (s2_) * 8);                     \
-        fa[set_][1] = *reinterpret_cast<const f16x8*>(Abuf + (ao_) + 16 + (s2_) * 8);                \
+        const unsigned mb_ = (am[(rt_) / 3] >> (9 * ((rt_) % 3) + (tap_))) & 1u;                     \
+        const int o_ = mb_ ? aoff0 + WIDE_ROWOFF(rt_) * LDK + (shift_) : zoff;                       \
+        fa[slot_][0] = *reinterpret_cast<const f16x8*>(Abuf + o_);                                   \
+        fa[slot_][1] = *reinterpret_cast<const f16x8*>(Abuf + o_ + 16);                              \
     }
-#define WIDE_TAP_OFFSETS(dst_, tap_)                                                                 \
-    {                                                                                                \
-        const int dh_ = (tap_) / 3 - 1, dw_ = (tap_) - ((tap_) / 3) * 3 - 1;                         \
-        const int shift_ = (dh_ * W + dw_) * LDK;                                                    \
-        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)                                        \
-            dst_[mt_] = ((amask[mt_] >> (tap_)) & 1u) ? aoff[mt_] + shift_ : zoff;                   \
-    }
-#define WIDE_GROUP(set_, fbs_, mt_)                                                                  \
+    // one tile step: row tile rt_ x the phase's two column tiles ct0_, ct0_ + 1: hi*hi, hi*lo, lo*hi
+#define WIDE_STEP(fas_, fbs_, rt_, ct0_)                                                             \
     if (!dbg_no_mfma) {                                                                              \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < NT; ++nt_) {                                      \
-            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set_][0], fb[fbs_][nt_][0], acc[mt_][nt_], 0, 0, 0); \
-            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set_][0], fb[fbs_][nt_][1], acc[mt_][nt_], 0, 0, 0); \
-            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set_][1], fb[fbs_][nt_][0], acc[mt_][nt_], 0, 0, 0); \
-        }                                                                                            \
+        acc[rt_][(ct0_)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fas_][0], fb[fbs_][0][0], acc[rt_][(ct0_)], 0, 0, 0);         \
+        acc[rt_][(ct0_) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fas_][0], fb[fbs_][1][0], acc[rt_][(ct0_) + 1], 0, 0, 0); \
+        acc[rt_][(ct0_)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fas_][0], fb[fbs_][0][1], acc[rt_][(ct0_)], 0, 0, 0);         \
+        acc[rt_][(ct0_) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fas_][0], fb[fbs_][1][1], acc[rt_][(ct0_) + 1], 0, 0, 0); \
+        acc[rt_][(ct0_)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fas_][1], fb[fbs_][0][0], acc[rt_][(ct0_)], 0, 0, 0);         \
+        acc[rt_][(ct0_) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fas_][1], fb[fbs_][1][0], acc[rt_][(ct0_) + 1], 0, 0, 0); \
     }
 
-    f16x8 fa[2][2], fb[2][NT][2];
-    if constexpr (W2) {
-        // Image width 2: for w = 0 the dw = -1 column of the kernel only sees zero padding, for w = 1 the dw = +1
-        // column.  With the rows permuted by parity (above), a kernel row costs: the centre tap on all four tiles,
-        // the dw = +1 tap on the even tiles, the dw = -1 tap on the odd tiles -- 16 tile steps instead of 24, only
-        // all-zero products dropped.  Loop body = one kernel row = six K=16 half-taps (centre, +1, -1) x (s2 0, 1).
-        const int nrows = nchunks * 3;
-        int aoc[MT], aos[MT];
-#define W2_ROW_OFFSETS(kr_)                                                                          \
-        {                                                                                            \
-            const int sh_ = ((kr_) - 1) * W * LDK;                                                   \
-            _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) {                                  \
-                aoc[mt_] = ((amask[mt_] >> ((kr_) * 3 + 1)) & 1u) ? aoff[mt_] + sh_ : zoff;          \
-                const int ts_ = (mt_ & 1) ? (kr_) * 3 : (kr_) * 3 + 2;                               \
-                aos[mt_] = ((amask[mt_] >> ts_) & 1u) ? aoff[mt_] + sh_ + ((mt_ & 1) ? -LDK : LDK) : zoff; \
-            }                                                                                        \
-        }
-        WIDE_LOAD_B(0, 0, 1, 0)
+    const int nrows = nchunks * 3;            // loop trips: one kernel row (3 taps) of one chunk each
+    f16x8 fa[FAR][2], fb[FBR][2][2];
+    // slab-row shift (floats) of tap (kernel row kr_, column index dwi_ = dw + 1)
+#define WIDE_SHIFT(kr_, dwi_) ((((kr_) - 1) * W + ((dwi_) - 1)) * LDK)
+
+    if constexpr (!W2) {
+        // phase ph of a kernel row: tap column ph / NT, column-tile pair ph % NT
+        WIDE_LOAD_B(0, 0, 0, 0)
         WIDE_LOAD_A(0)
         WIDE_STAGE_A()
         __syncthreads();
         WIDE_STAMP(2)
-        W2_ROW_OFFSETS(0)
-        WIDE_LOAD_FA(0, aoc[0], 0)
+        WIDE_LOAD_FA(0, 0, WIDE_SHIFT(0, 0), 0)
+        WIDE_LOAD_FA(1, 0, WIDE_SHIFT(0, 0), 1)
         int chunk = 0, kr = 0;
         for (int r = 0; r < nrows; ++r) {
             int nkr = kr + 1, nchunk = chunk;
@@ -298,158 +283,173 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
             const bool have_next = (r + 1 < nrows);
             const bool next_A = have_next && (nkr == 0);
             const int bkr = have_next ? nkr : kr, bchunk = have_next ? nchunk : chunk;   // B prefetch past this row (last row: re-read)
-            const int tc = kr * 3 + 1, tp = kr * 3 + 2, tm = kr * 3;
-            W2_ROW_OFFSETS(kr)
-            const int aoc_n0 = ((amask[0] >> (nkr * 3 + 1)) & 1u) ? aoff[0] + (nkr - 1) * W * LDK : zoff;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int k = q < 8 ? q / 4 : 2 + (q - 8) / 2;                          // half-tap 0..5
-                const int mt = q < 8 ? q % 4 : (k < 4 ? 0 : 1) + 2 * ((q - 8) % 2);     // tile of this step
-                if (q == 0) { WIDE_LOAD_B(1, chunk, tc, 1) }
-                if (q == 4) { WIDE_LOAD_B(0, chunk, tp, 0) }
-                if (q == 8) { WIDE_LOAD_B(1, chunk, tp, 1) }
-                if (q == 10) { WIDE_LOAD_B(0, chunk, tm, 0) }
-                if (q == 12) { WIDE_LOAD_B(1, chunk, tm, 1) }
-                if (q == 14) { WIDE_LOAD_B(0, bchunk, bkr * 3 + 1, 0) }
-                if (q + 1 < 16) {
-                    const int qn = q + 1;
-                    const int kn = qn < 8 ? qn / 4 : 2 + (qn - 8) / 2;
-                    const int mtn = qn < 8 ? qn % 4 : (kn < 4 ? 0 : 1) + 2 * ((qn - 8) % 2);
-                    WIDE_LOAD_FA(qn & 1, (kn < 2 ? aoc[mtn] : aos[mtn]), kn & 1)
-                } else if (have_next && !next_A) {
-                    WIDE_LOAD_FA(0, aoc_n0, 0)
+            for (int ph = 0; ph < PH; ++ph) {
+                if (ph + 1 < PH) {
+                    WIDE_LOAD_B((ph + 1) % FBR, chunk, kr * 3 + (ph + 1) / NT, (ph + 1) % NT)
+                } else {
+                    WIDE_LOAD_B((ph + 1) % FBR, bchunk, bkr * 3, 0)
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                WIDE_GROUP(q & 1, k & 1, mt)
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int G = ph * RT + rt;           // tile step of this row; A slot G % 3, prefetch for step G + 2
+                    if (G + 2 < PH * RT) {
+                        const int dwi2 = ((G + 2) / RT) / NT;
+                        WIDE_LOAD_FA((G + 2) % FAR, kr * 3 + dwi2, WIDE_SHIFT(kr, dwi2), (G + 2) % RT)
+                    } else if (have_next && !next_A) {
+                        WIDE_LOAD_FA((G + 2) % FAR, nkr * 3, WIDE_SHIFT(nkr, 0), G + 2 - PH * RT)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WIDE_STEP(G % FAR, ph % FBR, rt, (ph % NT) * 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (next_A) {
+                WIDE_LOAD_A(nchunk)             // in flight across the barrier
+                __syncthreads();                // every wave is done reading the slab of this chunk
+                WIDE_STAGE_A()
+                __syncthreads();
+                WIDE_LOAD_FA(0, 0, WIDE_SHIFT(0, 0), 0)
+                WIDE_LOAD_FA(1, 0, WIDE_SHIFT(0, 0), 1)
+            }
+            kr = nkr;
+            chunk = nchunk;
+        }
+    } else {
+        // Image width 2: for w = 0 the dw = -1 column of the kernel only sees zero padding, for w = 1 the dw = +1
+        // column.  Kernel row = 6 phases: centre tap on all 8 row tiles (x 2 column pairs), dw = +1 on the even
+        // tiles, dw = -1 on the odd tiles: 32 tile steps instead of 48, only all-zero products dropped.
+        //   step q:  0..7 (centre, pair 0)   8..15 (centre, pair 1)   16..19 / 20..23 (+1, even tiles, pair 0 / 1)
+        //            24..27 / 28..31 (-1, odd tiles, pair 0 / 1)
+        WIDE_LOAD_B(0, 0, 1, 0)
+        WIDE_LOAD_A(0)
+        WIDE_STAGE_A()
+        __syncthreads();
+        WIDE_STAMP(2)
+        WIDE_LOAD_FA(0, 1, WIDE_SHIFT(0, 1), 0)
+        WIDE_LOAD_FA(1, 1, WIDE_SHIFT(0, 1), 1)
+        int chunk = 0, kr = 0;
+        for (int r = 0; r < nrows; ++r) {
+            int nkr = kr + 1, nchunk = chunk;
+            if (nkr == 3) { nkr = 0; nchunk = chunk + 1; }
+            const bool have_next = (r + 1 < nrows);
+            const bool next_A = have_next && (nkr == 0);
+            const int bkr = have_next ? nkr : kr, bchunk = have_next ? nchunk : chunk;
+            // (three plain loop nests with affine indices rather than one 32-step loop with a step table: the
+            //  accumulator array only stays in registers if every index folds in the early unroll)
+            // ---- centre tap, all row tiles: steps q = 0..15 ----
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3 + 1, 1) } else { WIDE_LOAD_B(0, chunk, kr * 3 + 2, 0) }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int q = cp * 8 + rt;
+                    if (q + 2 < 16) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 1, WIDE_SHIFT(kr, 1), (q + 2) % 8) }
+                    else { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 2, WIDE_SHIFT(kr, 2), 2 * (q + 2 - 16)) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WIDE_STEP(q % FAR, cp, rt, cp * 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- dw = +1 on the even row tiles (w = 0 positions): steps 16..23 ----
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3 + 2, 1) } else { WIDE_LOAD_B(0, chunk, kr * 3, 0) }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = 16 + cp * 4 + i;
+                    if (q + 2 < 24) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 2, WIDE_SHIFT(kr, 2), 2 * ((q + 2 - 16) % 4)) }
+                    else { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), 2 * (q + 2 - 24) + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WIDE_STEP(q % FAR, cp, 2 * i, cp * 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- dw = -1 on the odd row tiles (w = 1 positions): steps 24..31 ----
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3, 1) } else { WIDE_LOAD_B(0, bchunk, bkr * 3 + 1, 0) }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = 24 + cp * 4 + i;
+                    if (q + 2 < 32) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), 2 * ((q + 2 - 24) % 4) + 1) }
+                    else if (have_next && !next_A) { WIDE_LOAD_FA((q + 2) % FAR, nkr * 3 + 1, WIDE_SHIFT(nkr, 1), q + 2 - 32) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WIDE_STEP(q % FAR, cp, 2 * i + 1, cp * 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (next_A) {
                 WIDE_LOAD_A(nchunk)
                 __syncthreads();
                 WIDE_STAGE_A()
                 __syncthreads();
-                WIDE_LOAD_FA(0, aoc_n0, 0)
+                WIDE_LOAD_FA(0, 1, WIDE_SHIFT(0, 1), 0)
+                WIDE_LOAD_FA(1, 1, WIDE_SHIFT(0, 1), 1)
             }
             kr = nkr;
             chunk = nchunk;
         }
-#undef W2_ROW_OFFSETS
-    } else {
-    const int niter = nchunks * 9;
-
-    int ao[MT], aon[MT];
-    WIDE_LOAD_B(0, 0, 0, 0)
-    WIDE_LOAD_A(0)
-    WIDE_STAGE_A()
-    __syncthreads();
-    WIDE_STAMP(2)
-    WIDE_TAP_OFFSETS(ao, 0)
-    WIDE_LOAD_FA(0, ao[0], 0)
-
-    int chunk = 0, tap = 0;
-    for (int it = 0; it < niter; ++it) {
-        int ntap = tap + 1, nchunk = chunk;
-        if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
-        const bool have_next = (it + 1 < niter);
-        const bool next_A = have_next && (ntap == 0);
-        WIDE_FINE()
-        // ---- K = 16 half-tap 0 (B set 0; the loads of set 1 fly meanwhile) ----
-        WIDE_LOAD_B(1, chunk, tap, 1)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt < MT - 1) WIDE_LOAD_FA((mt + 1) & 1, ao[mt + 1], 0) else WIDE_LOAD_FA(0, ao[0], 1)
-            __builtin_amdgcn_sched_barrier(0);
-            WIDE_GROUP(mt & 1, 0, mt)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        WIDE_FINE()
-        // ---- half-tap 1 (B set 1; set 0 is refilled for the next tap) ----
-        // unconditional (the last iteration re-reads its own block): a branch here would make the compiler wait
-        // with vmcnt(0), i.e. for these loads too, before the MFMAs of this half-tap
-        WIDE_LOAD_B(0, (have_next ? nchunk : chunk), (have_next ? ntap : tap), 0)
-        WIDE_TAP_OFFSETS(aon, ntap)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt < MT - 1) WIDE_LOAD_FA((mt + 1) & 1, ao[mt + 1], 1) else if (have_next && !next_A) WIDE_LOAD_FA(0, aon[0], 0)
-            __builtin_amdgcn_sched_barrier(0);
-            WIDE_GROUP(mt & 1, 1, mt)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        WIDE_FINE()
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ao[mt] = aon[mt];
-        if (next_A) {
-            WIDE_LOAD_A(nchunk)             // in flight across the barrier
-            __syncthreads();                // every wave is done reading the slab of this chunk
-            WIDE_STAGE_A()
-            __syncthreads();
-            WIDE_LOAD_FA(0, ao[0], 0)
-        }
-        WIDE_FINE()
-        tap = ntap;
-        chunk = nchunk;
-    }
     }
 #undef WIDE_LOAD_A
 #undef WIDE_STAGE_A
 #undef WIDE_LOAD_B
 #undef WIDE_LOAD_FA
-#undef WIDE_TAP_OFFSETS
-#undef WIDE_GROUP
+#undef WIDE_STEP
+#undef WIDE_SHIFT
     WIDE_STAMP(3)
     __syncthreads();          // the epilogue re-uses the slab's LDS: every wave must be done reading A fragments
 
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= DESCALE;
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] *= DESCALE;
 
     // ---- epilogue: GroupNorm partial sums (fp32 per 4-row unit -> fp64 per sample, fixed order), then the
     //      tile through LDS in two halves so that every lane stores 16 bytes ----
+    // accumulator layout: lane (l16, kg), register j of tile (rt, ct) = row 16 rt + 4 kg + j, column 16 ct + l16
     constexpr int HROWS = WM * 64;                       // rows per half
     float* otile = smem;                                 // [HROWS][N_T]
     float* srow = smem + HROWS * N_T;                    // [M_T / 4][WN][2]
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int rt = 0; rt < RT; ++rt) {
+        // the lane's four registers are one 4-row unit (W2: rows 2 apart inside one 8-row block -> slot unit
+        // 2 (block) + parity; a sample is still a contiguous run of HW / 4 slot units because HW % 8 == 0)
+        const int unit = wm * 32 + (W2 ? (rt >> 1) * 8 + 2 * kg + (rt & 1) : rt * 4 + kg);
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // 4-row unit of this register quad (W2: the quad's rows are 2 apart inside one 8-row block -> slot unit
-            // 2 (block) + parity; a sample is still a contiguous run of HW / 4 slot units because HW % 8 == 0)
-            const int r0 = W2 ? 4 * (wm * 32 + (mt >> 1) * 16 + 4 * g + 2 * kh + (mt & 1)) : wm * MT * 32 + mt * 32 + 8 * g + 4 * kh;
-            float s1 = 0.f, s2 = 0.f;
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = acc[mt][nt][4 * g + j];
-                    s1 += v;
-                    s2 += v * v;
-                }
-            s1 = half_sum_dpp(s1);
-            s2 = half_sum_dpp(s2);
-            if (li == 31) {
-                srow[((r0 >> 2) * WN + wn) * 2] = s1;
-                srow[((r0 >> 2) * WN + wn) * 2 + 1] = s2;
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[rt][ct][j];
+                s1 += v;
+                s2 += v * v;
             }
+        s1 = row16_sum_dpp(s1);
+        s2 = row16_sum_dpp(s2);
+        if (l16 == 0) {
+            srow[(unit * WN + wn) * 2] = s1;
+            srow[(unit * WN + wn) * 2 + 1] = s2;
         }
+    }
 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
 #pragma unroll
-        for (int mq = 0; mq < 2; ++mq)
+        for (int rq = 0; rq < 4; ++rq) {
+            const int rt = 4 * h + rq;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col_l = wn * NT * 32 + nt * 32 + li;
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col_l = wn * NT * 32 + ct * 16 + l16;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ri = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    const int row_l = W2 ? wm * 64 + 2 * ri + mq : wm * 64 + mq * 32 + ri;
-                    otile[row_l * N_T + col_l] = acc[2 * h + mq][nt][r];
+                for (int j = 0; j < 4; ++j) {
+                    // row inside the wave's half (64 rows): W2 (rt>>1 - 2h) 32 + 2 (4 kg + j) + parity, else rq 16 + 4 kg + j
+                    const int rw = W2 ? ((rt >> 1) - 2 * h) * 32 + 2 * (4 * kg + j) + (rt & 1) : rq * 16 + 4 * kg + j;
+                    otile[(wm * 64 + rw) * N_T + col_l] = acc[rt][ct][j];
                 }
             }
+        }
         __syncthreads();
         if (h == 0) WIDE_STAMP(4)
         if (h == 0) {
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
             const int ups = HW >> 2;                                   // 4-row units per sample
             const bool whole = (HW % M_T == 0);                        // the tile lies inside one sample
             const bool aligned = whole || (M_T % HW == 0 && (ups & (ups - 1)) == 0);
-            if (M_T == 256 && aligned) {
+            if (aligned) {
                 // one lane per unit, fp64 butterfly inside each sample's (aligned, power-of-two) lane segment:
                 // fixed order, position-independent -> deterministic and identical for every sample
                 if (wave == 0) {
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 #pragma unroll 4
         for (int p = 0; p < HROWS / RPP; ++p) {
             const int lr = p * RPP + r0;
-            const int row = m0 + (lr >> 6) * (MT * 32) + h * 64 + (lr & 63);
+            const int row = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
             if (row < M) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(otile + lr * N_T + c4o * 4);
                 *reinterpret_cast<f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4o * 4) = v;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     }
     WIDE_STAMP(5)
 #undef WIDE_STAMP
-#undef WIDE_FINE
+#undef WIDE_ROWOFF
 }
 
 template <int NT, int PRO, bool W2 = false>

@@ -61,24 +61,23 @@ double gemm_flops(const GemmArgs& a);
 bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g);
 hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s);
 
-// Fragment-order copy of split-format weights [taps][N][K] for conv_wide.hip: one 1-KiB block per MFMA B operand,
-//   block ((tap K/32 + chunk) N/32 + nb) x {K=16 step s2} x {hi, lo},  lane (kh 32 + li) -> 16 bytes =
-//   8 fp16 of row nb 32 + li, k = chunk 32 + s2 16 + kh 8 ..  -- so a wave's operand load is one coalesced
-//   global_load_dwordx4.  Same bytes as the split array, permuted.  (N % 32 == 0, K % 32 == 0.)
+// Fragment-order copy of split-format weights [taps][N][K] for conv_wide.hip (v_mfma_f32_16x16x32_f16 B operands):
+//   block ((tap K/32 + chunk) N/16 + nb16) x {hi, lo} of 1 KiB; lane (kg 16 + l16) -> 16 bytes = 8 fp16 of row
+//   nb16 16 + l16, k = chunk 32 + kg 8 .. -- so a wave's operand load is one coalesced global_load_dwordx4.
+//   Same bytes as the split array, permuted.  (N % 16 == 0, K % 32 == 0.)
 inline std::vector<float> frag_order_weights(const std::vector<float>& split, int taps, int N, int K) {
     std::vector<float> out(split.size());
-    const int nch = K / 32, nbn = N / 32;
+    const int nch = K / 32, nbn = N / 16;
     for (int t = 0; t < taps; ++t)
         for (int c = 0; c < nch; ++c)
             for (int nb = 0; nb < nbn; ++nb)
-                for (int s2 = 0; s2 < 2; ++s2)
-                    for (int part = 0; part < 2; ++part)
-                        for (int kh = 0; kh < 2; ++kh)
-                            for (int li = 0; li < 32; ++li) {
-                                const size_t dst = (((((size_t)(t * nch + c) * nbn + nb) * 2 + s2) * 2 + part) * 64 + kh * 32 + li) * 4;
-                                const size_t src = ((size_t)t * N + nb * 32 + li) * K + c * 32 + part * 16 + s2 * 8 + kh * 4;
-                                for (int j = 0; j < 4; ++j) out[dst + j] = split[src + j];
-                            }
+                for (int part = 0; part < 2; ++part)
+                    for (int kg = 0; kg < 4; ++kg)
+                        for (int l16 = 0; l16 < 16; ++l16) {
+                            const size_t dst = ((((size_t)(t * nch + c) * nbn + nb) * 2 + part) * 64 + kg * 16 + l16) * 4;
+                            const size_t src = ((size_t)t * N + nb * 16 + l16) * K + c * 32 + part * 16 + kg * 4;
+                            for (int j = 0; j < 4; ++j) out[dst + j] = split[src + j];
+                        }
     return out;
 }
 

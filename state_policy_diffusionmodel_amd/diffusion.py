@@ -105,6 +105,28 @@ class Diffusion_DDPM:
         self._engine: Optional[SpdmEngine] = None
         self._engine_key = None
 
+    # ------------------------------------------------------------------------------------------
+    _HPARAM_KEYS = ("noise_steps", "obs_horizon", "pred_horizon", "observation_dim", "prediction_dim", "learning_rate",
+                    "model", "noise_scheduler_type", "inpaint_horizon", "step_size")
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, hparams_file=None, map_location=None, **kwargs):
+        """Lightning's ``LightningModule.load_from_checkpoint(ckpt, hparams_file=yaml)`` as generate.py:25,27 and
+        run_predictions.py call it: constructor arguments from ``hparams.yaml`` (``save_hyperparameters()`` of
+        models/diffusion_ddpm.py:37), U-Net tensors from the checkpoint's ``noise_estimator.*`` entries.  The vision
+        encoder's tensors are not consumed here (the front end is a pluggable callable)."""
+        from .weights import check_state_dict, fetch_hyperparams_from_yaml, load_checkpoint_state_dict
+        hp = dict(fetch_hyperparams_from_yaml(hparams_file)) if hparams_file else {}
+        ctor = {k: hp[k] for k in cls._HPARAM_KEYS if k in hp}
+        if isinstance(hp.get("vision_encoder"), str) or hp.get("vision_encoder") is None:
+            pass                                   # a name (e.g. 'resnet18') in the yaml is not a callable: ignored
+        ctor.update(kwargs)
+        sd, _other = load_checkpoint_state_dict(str(checkpoint_path))
+        attention = ctor.get("model", "UNet") != "UNet_FilmnoAttention"
+        cond_dim = int(ctor.get("observation_dim", 2)) * int(ctor.get("obs_horizon", 10))
+        check_state_dict(sd, cond_dim, attention=attention)
+        return cls(state_dict=sd, **ctor)
+
     # Lightning look-alikes used by callers (generate.py:36)
     def eval(self):
         return self
@@ -207,17 +229,23 @@ class Diffusion_DDIM(Diffusion_DDPM):
     pass
 
 
-def load_model(model_name: str, state_dict=None, num_of_ddim_steps: int = 100, **hparams):
-    """generate.py:23-37, minus Lightning's checkpoint reader: build the sampler and, for DDIM,
+def load_model(model_name: str, checkpoint_path=None, hparams_path=None, num_of_ddim_steps: int = 100, *,
+               state_dict=None, **hparams):
+    """generate.py:23-37: build the sampler from a checkpoint + hparams.yaml (same positional signature as the
+    reference) -- or from an in-memory ``state_dict`` / random init when no checkpoint is given -- and, for DDIM,
     overwrite scheduler and noise_steps exactly as the reference's loader does."""
-    if model_name == "DDPM":
-        model = Diffusion_DDPM(state_dict=state_dict, **hparams)
-    elif model_name == "DDIM":
-        model = Diffusion_DDIM(state_dict=state_dict, **hparams)
+    if model_name not in ("DDPM", "DDIM"):
+        raise ValueError("model_name must be 'DDPM' or 'DDIM'")
+    cls = Diffusion_DDPM if model_name == "DDPM" else Diffusion_DDIM
+    if checkpoint_path is not None and not isinstance(checkpoint_path, (str, bytes)) and not hasattr(checkpoint_path, "__fspath__"):
+        state_dict, checkpoint_path = checkpoint_path, None        # load_model(name, state_dict) of earlier callers
+    if checkpoint_path is not None:
+        model = cls.load_from_checkpoint(checkpoint_path, hparams_file=hparams_path, **hparams)
+    else:
+        model = cls(state_dict=state_dict, **hparams)
+    if model_name == "DDIM":
         model.noise_scheduler = DDIMScheduler(num_train_timesteps=num_of_ddim_steps, beta_schedule="linear",
                                               clip_sample=False, prediction_type="epsilon")
         model.noise_steps = num_of_ddim_steps
-    else:
-        raise ValueError("model_name must be 'DDPM' or 'DDIM'")
     model.eval()
     return model

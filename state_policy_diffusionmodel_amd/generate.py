@@ -31,6 +31,7 @@ def parse_arguments(argv=None):
     p.add_argument("--seed", type=int, default=125, help="Random seed")
     # extensions
     p.add_argument("--checkpoint", type=str, default=None, help="state_dict file with noise_estimator.* tensors")
+    p.add_argument("--hparams", type=str, default=None, help="hparams.yaml written next to the checkpoint (overrides the size flags)")
     p.add_argument("--model", type=str, default="UNet_Film")
     p.add_argument("--obs_horizon", type=int, default=10)
     p.add_argument("--pred_horizon", type=int, default=15)
@@ -47,14 +48,14 @@ def parse_arguments(argv=None):
 def main(argv=None):
     args = parse_arguments(argv)
     torch.manual_seed(args.seed)
-    sd = None
-    if args.checkpoint:
-        ck = torch.load(args.checkpoint, map_location="cpu", weights_only=True)
-        sd = ck.get("state_dict", ck)
-    model = load_model(args.model_name, state_dict=sd, num_of_ddim_steps=args.ddim_steps,
-                       noise_steps=args.noise_steps, obs_horizon=args.obs_horizon, pred_horizon=args.pred_horizon,
-                       observation_dim=args.observation_dim, prediction_dim=args.prediction_dim, model=args.model,
-                       inpaint_horizon=args.inpaint_horizon, max_batch=args.batch_size)
+    size = dict(noise_steps=args.noise_steps, obs_horizon=args.obs_horizon, pred_horizon=args.pred_horizon,
+                observation_dim=args.observation_dim, prediction_dim=args.prediction_dim, model=args.model,
+                inpaint_horizon=args.inpaint_horizon)
+    if args.hparams:            # generate.py:46-58 of the reference: everything comes from tb_logs/version_*/hparams.yaml
+        size = {}
+    model = load_model(args.model_name, args.checkpoint or None, args.hparams, num_of_ddim_steps=args.ddim_steps,
+                       max_batch=args.batch_size, **size)
+    args.obs_horizon, args.observation_dim = model.obs_horizon, model.observation_dim
     B, oh = args.batch_size, args.obs_horizon
     g = torch.Generator().manual_seed(args.seed)
     batch = {"position": torch.rand(B, oh, 2, generator=g) * 2 - 1, "velocity": torch.rand(B, oh, 2, generator=g) * 2 - 1,

@@ -192,3 +192,76 @@ def blob_sha256(sd) -> str:
         h.update(name.encode())
         h.update(np.ascontiguousarray(arr, dtype=np.float32).tobytes())
     return h.hexdigest()
+
+
+# ---- checkpoint ingestion ---------------------------------------------------------
+def fetch_hyperparams_from_yaml(file_path: str) -> dict:
+    """utils/data_utils.py:5-8 of the reference: the Lightning ``hparams.yaml`` is plain ``key: value`` YAML."""
+    import yaml
+    with open(file_path, "r") as fh:
+        return yaml.safe_load(fh) or {}
+
+
+def load_checkpoint_state_dict(checkpoint_path: str, prefix: str = "noise_estimator."):
+    """The U-Net tensors of a reference checkpoint (Lightning ``.ckpt``: ``{'state_dict': {'noise_estimator.*': ...,
+    'vision_encoder.*': ...}, ...}``; generate.py:23-26 reads it through ``load_from_checkpoint``), or of a bare
+    ``state_dict`` file, with the ``noise_estimator.`` prefix removed.
+
+    Only loaders that execute nothing from the file are used (``torch.load(weights_only=True)``); a checkpoint the
+    safe loader refuses is reported, never unpickled.  Returns ``(unet_state_dict, other_keys)``."""
+    import torch
+    try:
+        ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    except Exception as e:  # noqa: BLE001 - re-raised with the policy spelled out
+        raise RuntimeError(f"{checkpoint_path}: torch.load(weights_only=True) refused this file ({e}); "
+                           "re-save it as a plain state_dict (tensors only) -- it will not be unpickled here") from e
+    sd = ck.get("state_dict", ck) if isinstance(ck, dict) else None
+    if not isinstance(sd, dict) or not sd:
+        raise RuntimeError(f"{checkpoint_path}: no state_dict found")
+    unet, other = OrderedDict(), []
+    has_prefix = any(k.startswith(prefix) for k in sd)
+    for k, v in sd.items():
+        if has_prefix:
+            if k.startswith(prefix):
+                unet[k[len(prefix):]] = v
+            else:
+                other.append(k)
+        else:
+            unet[k] = v
+    return unet, other
+
+
+def check_state_dict(sd, global_cond_dim: int, time_dim: int = 256, attention: bool = True) -> None:
+    """Key-for-key / shape-for-shape check against the UNet_Film parameter inventory (the same 162-tensor inventory
+    the golden fixtures pin against the reference module, tools/make_golden.py)."""
+    spec = unet_film_param_spec(global_cond_dim, time_dim=time_dim, attention=attention)
+    want = dict(spec)
+    missing = [k for k in want if k not in sd]
+    extra = [k for k in sd if k not in want and not k.endswith("num_batches_tracked")]
+    bad = [f"{k}: {tuple(sd[k].shape)} != {want[k]}" for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k])]
+    if missing or extra or bad:
+        raise ValueError("state_dict does not match UNet_Film"
+                         f"{'' if attention else '_noAttention'}(global_cond_dim={global_cond_dim}, time_dim={time_dim}): "
+                         f"missing {missing[:4]}{'...' if len(missing) > 4 else ''}, unexpected {extra[:4]}"
+                         f"{'...' if len(extra) > 4 else ''}, shape mismatches {bad[:4]}")
+
+
+# ---- data (un)normalisation the reference applies around the sampler (utils/data_utils.py:10-40) ----------------
+def normalize_data(data, stats):
+    ndata = (data - stats["min"]) / (stats["max"] - stats["min"])
+    return ndata * 2 - 1
+
+
+def unnormalize_data(ndata, stats):
+    ndata = (ndata + 1) / 2
+    return ndata * (stats["max"] - stats["min"]) + stats["min"]
+
+
+def normalize_position(sample, position_stats):
+    sample_normalized = normalize_data(sample, position_stats)
+    translation_vec = sample_normalized[0, :]
+    return (sample_normalized - translation_vec) / 2.0, translation_vec
+
+
+def unnormalize_position(nsample, translation_vec, position_stats):
+    return unnormalize_data(np.asarray(nsample) * 2.0 + translation_vec, position_stats)
