@@ -267,7 +267,79 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     // slab-row shift (floats) of tap (kernel row kr_, column index dwi_ = dw + 1)
 #define WIDE_SHIFT(kr_, dwi_) ((((kr_) - 1) * W + ((dwi_) - 1)) * LDK)
 
-    if constexpr (!W2) {
+    if constexpr (!W2 && NT == 2) {
+        // 128-wide tiles: one tap at a time with ALL four column tiles of the tap's weights in registers (two tap
+        // slots = 64 registers), so every A fragment is read from LDS once per tap and feeds 12 MFMAs; the next
+        // tap's weights are loaded a whole tap (96 MFMAs) ahead.  Loop body = two taps (compile-time slots); the
+        // flat tap sequence over (chunk, tap) has even length because K % 64 == 0 (checked on the host).
+        f16x8 fbt[2][4][2], fat[2][2];
+#define TAP_LOAD_B(slot_, chunk_, tap_)                                                              \
+        if (!dbg_no_wload) {                                                                         \
+            const float* p_ = wfl + (size_t)((tap_) * nchunks + (chunk_)) * wtap;                    \
+            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                      \
+                fbt[slot_][c_][0] = *reinterpret_cast<const f16x8*>(p_ + c_ * 512);                  \
+                fbt[slot_][c_][1] = *reinterpret_cast<const f16x8*>(p_ + c_ * 512 + 256);            \
+            }                                                                                        \
+        }
+#define TAP_LOAD_FA(slot_, tap_, shift_, rt_)                                                        \
+        {                                                                                            \
+            const unsigned mb_ = (am[(rt_) / 3] >> (9 * ((rt_) % 3) + (tap_))) & 1u;                 \
+            const int o_ = mb_ ? aoff0 + WIDE_ROWOFF(rt_) * LDK + (shift_) : zoff;                   \
+            fat[slot_][0] = *reinterpret_cast<const f16x8*>(Abuf + o_);                              \
+            fat[slot_][1] = *reinterpret_cast<const f16x8*>(Abuf + o_ + 16);                         \
+        }
+#define TAP_SHIFT(tap_) ((((tap_) / 3 - 1) * W + ((tap_) - ((tap_) / 3) * 3 - 1)) * LDK)
+        const int ntaps = nchunks * 9;
+        TAP_LOAD_B(0, 0, 0)
+        WIDE_LOAD_A(0)
+        WIDE_STAGE_A()
+        __syncthreads();
+        WIDE_STAMP(2)
+        TAP_LOAD_FA(0, 0, TAP_SHIFT(0), 0)
+        int chunk = 0, tap = 0;
+        for (int tt = 0; tt < ntaps; tt += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                int ntap = tap + 1, nchunk = chunk;
+                if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
+                const bool have_next = (tt + half + 1 < ntaps);
+                const bool next_A = have_next && (ntap == 0);
+                // unconditional prefetch (the last tap re-reads its own weights): see the header
+                TAP_LOAD_B(1 - half, (have_next ? nchunk : chunk), (have_next ? ntap : tap))
+                const int sh = TAP_SHIFT(tap), nsh = TAP_SHIFT(ntap);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (rt + 1 < RT) { TAP_LOAD_FA((rt + 1) & 1, tap, sh, rt + 1) }
+                    else if (have_next && !next_A) { TAP_LOAD_FA(0, ntap, nsh, 0) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!dbg_no_mfma) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][0], fbt[half][c][0], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][0], fbt[half][c][1], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][1], fbt[half][c][0], acc[rt][c], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (next_A) {
+                    WIDE_LOAD_A(nchunk)             // in flight across the barrier
+                    __syncthreads();                // every wave is done reading the slab of this chunk
+                    WIDE_STAGE_A()
+                    __syncthreads();
+                    TAP_LOAD_FA(0, 0, TAP_SHIFT(0), 0)
+                }
+                tap = ntap;
+                chunk = nchunk;
+            }
+        }
+#undef TAP_LOAD_B
+#undef TAP_LOAD_FA
+#undef TAP_SHIFT
+    } else if constexpr (!W2) {
         // phase ph of a kernel row: tap column ph / NT, column-tile pair ph % NT
         WIDE_LOAD_B(0, 0, 0, 0)
         WIDE_LOAD_A(0)
@@ -550,6 +622,7 @@ bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
     if (!ok) return false;
     // width-2 maps: only with the zero-tap skipping variant (otherwise conv_gemm.hip's W2 configuration does less work)
     if (wide_w2(a)) return g.n_tile == 128 && (a.HW & 7) == 0;
+    if (g.n_tile == 128 && a.K % 64 != 0) return false;      // the 128-wide loop walks taps in pairs
     return true;
 }
 
