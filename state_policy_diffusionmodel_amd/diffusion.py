@@ -216,11 +216,56 @@ class Diffusion_DDPM:
         act = observation_batch["action"][:, -self.inpaint_horizon:, :]
         return torch.cat([pos, act], dim=-1)
 
-    # training-side entry points of the reference that are NOT on the sampling path
-    def training_step(self, *a, **k):
-        raise NotImplementedError("training is out of scope of the MI355X hot path (SURVEY.md section 3.5)")
+    def prepare_prediction_batch(self, batch):
+        """models/diffusion_ddpm.py:300-315: the last pred_horizon entries of every modality."""
+        out = {}
+        for k in ("image", "position", "action", "velocity", "image_features"):
+            if k in batch:
+                out[k] = batch[k][:, self.obs_horizon:self.obs_horizon + self.pred_horizon].to(self.device).float()
+        return out
 
-    validation_step = training_step
+    def prepare_prediction_vectors(self, prediction_batch):
+        """models/diffusion_ddpm.py:332-338: x_0 = cat(position, action)."""
+        return torch.cat([prediction_batch["position"], prediction_batch["action"]], dim=-1)
+
+    # ==================== Validation (models/diffusion_ddpm.py:175-214) ====================
+    def validate(self, batch, *, x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """The reference's validation sampler: the first trajectory of the batch through the full loop; returns
+        ``(x_0 (1,1,H,D), observation_batch, inpaint_vector (1,1,inp_h,D))``."""
+        observation_batch = self.prepare_observation_batch(batch)
+        inpaint_vector = self.prepare_inpaint_vectors(observation_batch)[0:1].unsqueeze(1)
+        x_0 = self.sample(dict(observation_batch), x_T=x_T, noise=noise)
+        return x_0, observation_batch, inpaint_vector
+
+    # ==================== Training, forward half (models/diffusion_ddpm.py:140-172) ====================
+    def training_step(self, batch, batch_idx: int = 0, *, t: Optional[torch.Tensor] = None,
+                      noise: Optional[torch.Tensor] = None, return_parts: bool = False):
+        """The forward computation of the reference's ``training_step``: noising of the target window at a per-sample
+        timestep (``add_noise``), in-painting of the observed rows, ONE U-Net evaluation with ``t`` of shape (B,), MSE
+        against the noise.  The U-Net runs on the HIP path (``spdm_unet_forward`` with per-sample t); there is no
+        backward pass here -- the returned loss carries no graph (training itself is outside this path).
+        ``t`` / ``noise`` may be passed for reproducibility (the reference draws them with torch.randint / randn_like)."""
+        observation_batch = self.prepare_observation_batch(batch)
+        prediction_batch = self.prepare_prediction_batch(batch)
+        obs_cond = self.prepare_obs_cond_vectors(observation_batch).unsqueeze(1)            # (B,1,obs_h,obs_dim)
+        x_0 = self.prepare_prediction_vectors(prediction_batch).unsqueeze(1)               # (B,1,pred_h,pred_dim)
+        x_0_inpaint = self.prepare_inpaint_vectors(observation_batch).unsqueeze(1)         # (B,1,inp_h,pred_dim)
+        B = x_0.shape[0]
+        if t is None:
+            t = torch.randint(0, self.noise_steps, (B,), device=self.device)
+        t = t.to(self.device).long()
+        prediction_vector = torch.cat([x_0_inpaint, x_0], dim=2)                           # concat in time
+        if noise is None:
+            noise = torch.randn_like(prediction_vector)
+        noise = noise.to(self.device).float()
+        x_noisy = _as_spec(self.noise_scheduler).add_noise(prediction_vector, noise, t)
+        x_noisy = self.add_constraints(x_noisy, x_0_inpaint)
+        noise_estimated = self.noise_estimator(x_noisy, t, obs_cond)
+        loss = torch.mean((noise - noise_estimated) ** 2)                                  # nn.MSELoss, :49
+        return (loss, noise_estimated, x_noisy) if return_parts else loss
+
+    def validation_step(self, batch, batch_idx: int = 0, **kw):
+        return self.training_step(batch, batch_idx, **kw)
 
 
 class Diffusion_DDIM(Diffusion_DDPM):

@@ -58,3 +58,42 @@ def test_ddim_scheduler_swap_idiom():
     want = sample_loop(lambda x, t, y: unet_film_forward(sd, x, t, y, attention=False), "ddim", 6, 6, cond, x_T, None,
                        inp)
     assert float((out.cpu() - want).abs().max()) <= 1e-4
+
+
+def test_training_step_forward_half_and_validate_against_oracle():
+    """models/diffusion_ddpm.py:140-172 (forward only): add_noise at per-sample t -> inpaint -> U-Net(t:(B,)) -> MSE,
+    checked against the torch-CPU oracle on the same t / noise; validate() = the first trajectory through the loop."""
+    from oracle.scheduler_ref import LinearBetaSchedule
+    from state_policy_diffusionmodel_amd.diffusion import Diffusion_DDPM
+    g = torch.Generator().manual_seed(5)
+    obs_h, pred_h, inp_h, B = 3, 13, 3, 4
+    m = Diffusion_DDPM(noise_steps=50, obs_horizon=obs_h, pred_horizon=pred_h, observation_dim=11, prediction_dim=5,
+                       model="UNet_Film", inpaint_horizon=inp_h, weight_seed=8, max_batch=B)
+    batch = _batch(B, obs_h + pred_h, g)
+    t = torch.tensor([0, 7, 31, 49])
+    noise = torch.randn(B, 1, pred_h + inp_h, 5, generator=g)
+    loss, eps, x_noisy = m.training_step({k: v.clone() for k, v in batch.items()}, t=t, noise=noise, return_parts=True)
+    assert eps.shape == (B, 1, pred_h + inp_h, 5) and loss.ndim == 0
+    # oracle: the same forward process in torch on the CPU
+    obs = {k: v[:, :obs_h].float() for k, v in batch.items()}
+    cond = torch.cat([obs["position"], obs["action"], obs["velocity"], obs["image_features"]], -1).unsqueeze(1)
+    x0 = torch.cat([batch["position"][:, obs_h:], batch["action"][:, obs_h:]], -1).unsqueeze(1).float()
+    inp = torch.cat([obs["position"][:, -inp_h:], obs["action"][:, -inp_h:]], -1).unsqueeze(1)
+    pv = torch.cat([inp, x0], 2)
+    ac = LinearBetaSchedule(50).alphas_cumprod
+    a = ac[t].sqrt().view(B, 1, 1, 1)
+    b = (1 - ac[t]).sqrt().view(B, 1, 1, 1)
+    xn = a * pv + b * noise
+    xn[:, :, :inp_h, :] = inp
+    assert float((x_noisy.cpu() - xn).abs().max()) <= 1e-6
+    want = unet_film_forward(m.noise_estimator._sd, xn, t, cond)
+    assert float((eps.cpu() - want).abs().max()) <= 1e-4
+    assert abs(float(loss) - float(torch.mean((noise - want) ** 2))) <= 1e-5
+    # validate(): first trajectory only, like the reference
+    x_T = torch.rand(1, 1, pred_h + inp_h, 5, generator=g)
+    nz = torch.randn(50, 1, 1, pred_h + inp_h, 5, generator=g)
+    x0v, ob, iv = m.validate({k: v.clone() for k, v in batch.items()}, x_T=x_T.cuda(), noise=nz.cuda())
+    assert x0v.shape == (1, 1, pred_h + inp_h, 5) and iv.shape == (1, 1, inp_h, 5)
+    want_v = sample_loop(lambda x, tt, y: unet_film_forward(m.noise_estimator._sd, x, tt, y), "ddpm", 50, 50, cond[0:1],
+                         x_T, nz, inp[0:1])
+    assert float((x0v.cpu() - want_v).abs().max()) <= 1e-4
