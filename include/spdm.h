@@ -184,7 +184,9 @@ int  spdm_profile_read(spdm_handle* h, int64_t* launches, double* total_ms, doub
  * 1 GroupNorm, 2 GroupNorm+GELU; epi: 0 GN stats, 1 bias, 2 bias+GELU, 3 bias+residual; debug: ablation bits. */
 int  spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t taps,
                      int32_t pro, int32_t epi, int32_t split, int32_t iters, int32_t debug,
-                     double* ms_out /* [2]: ms per launch, max |out - exact-fp32 out| (debug == 0) */);
+                     double* ms_out /* [3]: ms per launch; max |out - exact-fp32 out|; worst deviation of the per-sample
+                                        GroupNorm mean (in sigmas) / variance (relative) the launch reported from the
+                                        values recomputed from its own output (both: debug == 0, else -1) */);
 
 /* Op-level test hook: d_y = GELU(d_x) evaluated with the device erf that the conv prologues use
  * (nn.GELU(), models/Unet_FiLmLayer.py:104). */

@@ -1166,7 +1166,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     const int HW = H * W, M = B * HW;
     const GemmGeom g = gemm_geometry(M, Cout, HW, taps, split);
     float *src = nullptr, *wgt = nullptr, *wgt32 = nullptr, *dst = nullptr, *dst2 = nullptr, *gb = nullptr, *resid = nullptr, *wfrag = nullptr;
-    double *st_in = nullptr, *st_out = nullptr;
+    double *st_in = nullptr, *st_out = nullptr, *st_out2 = nullptr;
     const size_t nsrc = (size_t)M * Cin, nw = (size_t)taps * Cout * Cin, ndst = (size_t)M * Cout;
     HIP_TRY(hipMalloc((void**)&src, nsrc * 4));
     HIP_TRY(hipMalloc((void**)&wgt, nw * 4));
@@ -1177,6 +1177,10 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     HIP_TRY(hipMalloc((void**)&gb, (size_t)(Cin + Cout) * 2 * 4));
     HIP_TRY(hipMalloc((void**)&st_in, (size_t)B * 2 * 8));
     HIP_TRY(hipMalloc((void**)&st_out, (size_t)B * g.slots * 2 * 8));
+    HIP_TRY(hipMemset(st_out, 0, (size_t)B * g.slots * 2 * 8));
+    const GemmGeom g2 = gemm_geometry(M, Cout, HW, taps, 0);
+    HIP_TRY(hipMalloc((void**)&st_out2, (size_t)B * g2.slots * 2 * 8));
+    HIP_TRY(hipMemset(st_out2, 0, (size_t)B * g2.slots * 2 * 8));
     {   // deterministic pseudo-random fill (values ~U(-1,1)); split weights are packed as at load time
         std::vector<float> hsrc(nsrc), hw(nw), hgb((size_t)(Cin + Cout) * 2);
         unsigned x = 12345u;
@@ -1238,10 +1242,10 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    double maxdiff = -1.0;
+    double maxdiff = -1.0, statdiff = -1.0;
     if (e == hipSuccess && debug == 0) {      // self-check: same data through the exact fp32-MFMA configuration
         GemmArgs b2 = a;
-        b2.split = 0; b2.wgt = wgt32; b2.wgt_frag = nullptr; b2.dst = dst2;
+        b2.split = 0; b2.wgt = wgt32; b2.wgt_frag = nullptr; b2.dst = dst2; b2.epi_stats = st_out2;
         e = launch_gemm(b2, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         std::vector<float> h1(ndst), h2(ndst);
@@ -1251,8 +1255,28 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
             maxdiff = 0.0;
             for (size_t i = 0; i < ndst; ++i) maxdiff = std::max(maxdiff, (double)std::fabs(h1[i] - h2[i]));
         }
+        if (e == hipSuccess && epi == EPI_STATS) {
+            // GroupNorm partials of the launch under test against totals recomputed (fp64, host) from ITS OWN output:
+            // checks the epilogue's slot bookkeeping and reductions independently of kernel-vs-kernel rounding
+            std::vector<double> s1((size_t)B * g.slots * 2);
+            e = hipMemcpy(s1.data(), st_out, s1.size() * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) {
+                statdiff = 0.0;
+                const double n = (double)HW * Cout;
+                for (int b = 0; b < B; ++b) {
+                    double t1 = 0.0, t2 = 0.0, r1 = 0.0, r2 = 0.0;
+                    for (int k = 0; k < g.slots; ++k) { t1 += s1[((size_t)b * g.slots + k) * 2]; t2 += s1[((size_t)b * g.slots + k) * 2 + 1]; }
+                    const float* p = h1.data() + (size_t)b * HW * Cout;
+                    for (size_t i = 0; i < (size_t)HW * Cout; ++i) { r1 += p[i]; r2 += (double)p[i] * p[i]; }
+                    const double m1 = t1 / n, mr = r1 / n, v1 = t2 / n - m1 * m1, vr = r2 / n - mr * mr;
+                    statdiff = std::max(statdiff, std::fabs(m1 - mr) / std::sqrt(std::max(vr, 1e-30)));
+                    statdiff = std::max(statdiff, std::fabs(v1 - vr) / std::max(vr, 1e-30));
+                }
+            }
+        }
     }
     ms_out[1] = maxdiff;
+    ms_out[2] = statdiff;
     if (d_stamps && getenv("SPDM_STAMP_DUMP")) {      // raw per-workgroup timeline of conv_wide (analysed offline)
         std::vector<unsigned long long> hs((size_t)65536 * 8);
         if (hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1273,7 +1297,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
         (void)hipFree(d_stamps);
     }
     (void)hipFree(wgt32); (void)hipFree(dst2); (void)hipFree(wfrag);
-    (void)hipFree(src); (void)hipFree(wgt); (void)hipFree(dst); (void)hipFree(resid); (void)hipFree(gb); (void)hipFree(st_in); (void)hipFree(st_out);
+    (void)hipFree(src); (void)hipFree(wgt); (void)hipFree(dst); (void)hipFree(resid); (void)hipFree(gb); (void)hipFree(st_in); (void)hipFree(st_out); (void)hipFree(st_out2);
     if (e != hipSuccess) return fail(SPDM_ERR_HIP, "bench_gemm: %s", hipGetErrorString(e));
     *ms_out = ms / iters;
     return SPDM_OK;

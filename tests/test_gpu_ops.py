@@ -41,6 +41,29 @@ def test_gemm_configurations_agree_with_exact_fp32_path():
         (8, 32, 8, 64, 192, 1, 0, 1), (8, 32, 8, 64, 64, 1, 0, 3), (8, 16, 4, 128, 128, 1, 0, 2), (5, 1, 1, 1376, 256, 1, 0, 1),
     ]
     for B, H, W, Cin, Cout, taps, pro, epi in cases:
-        ms = (ctypes.c_double * 2)()
+        ms = (ctypes.c_double * 3)()
         _lib.check(lib.spdm_bench_gemm(0, B, H, W, Cin, Cout, taps, pro, epi, 1, 1, 0, ms), "spdm_bench_gemm")
         assert 0.0 <= ms[1] <= 5e-5, ((B, H, W, Cin, Cout, taps, pro, epi), ms[1])
+        if epi == 0:
+            assert 0.0 <= ms[2] <= 1e-5, ((B, H, W, Cin, Cout, taps, pro, epi), "GroupNorm totals", ms[2])
+
+
+def test_wide_conv_kernel_shapes_against_exact_fp32_path():
+    """conv3x3_wide_kernel (conv_wide.hip: large-batch 3x3 convs of levels 0-2) against the exact fp32-MFMA kernel on
+    the same synthetic data, outputs AND per-sample GroupNorm totals: 128- and 64-wide tiles, all three prologues, the
+    width-2 zero-tap-skipping variant, ragged last tiles (M % 256 != 0), several samples per tile (HW = 128, 64, 32,
+    16), tiles inside one sample (HW = 512), and a sample length that is not a power of two (HW = 192: serial totals)."""
+    from state_policy_diffusionmodel_amd import _lib
+    lib = _lib.load()
+    cases = [  # B, H, W, Cin, Cout, taps, pro, epi      (M / 256 * Cout / n_tile >= 192 selects the wide kernel)
+        (200, 32, 8, 64, 128, 9, 0, 0), (193, 32, 8, 128, 128, 9, 2, 0), (400, 16, 8, 64, 128, 9, 1, 0),
+        (97, 64, 8, 64, 128, 9, 2, 0), (270, 24, 8, 64, 128, 9, 2, 0),
+        (771, 16, 4, 128, 128, 9, 2, 0), (1543, 8, 4, 64, 256, 9, 1, 0),
+        (200, 32, 8, 64, 64, 9, 2, 0), (387, 32, 8, 128, 64, 9, 1, 0), (1541, 16, 4, 64, 64, 9, 0, 0),
+        (3083, 8, 2, 128, 128, 9, 2, 0), (1601, 8, 2, 256, 256, 9, 0, 0), (1600, 16, 2, 64, 128, 9, 1, 0),
+    ]
+    for B, H, W, Cin, Cout, taps, pro, epi in cases:
+        ms = (ctypes.c_double * 3)()
+        _lib.check(lib.spdm_bench_gemm(0, B, H, W, Cin, Cout, taps, pro, epi, 1, 1, 0, ms), "spdm_bench_gemm")
+        assert 0.0 <= ms[1] <= 5e-5, ((B, H, W, Cin, Cout, taps, pro, epi), ms[1])
+        assert 0.0 <= ms[2] <= 1e-5, ((B, H, W, Cin, Cout, taps, pro, epi), "GroupNorm totals", ms[2])

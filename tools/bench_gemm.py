@@ -34,10 +34,10 @@ for n in names:
                 continue
         elif dn != "full" and "--ablate" not in sys.argv:
             continue
-        ms = (ctypes.c_double * 2)()
+        ms = (ctypes.c_double * 3)()
         rc = lib.spdm_bench_gemm(0, B, H, W, Cin, Cout, taps, pro, epi, split, 5, dv, ms)
         _lib.check(rc, "spdm_bench_gemm")
         out.append(f"{dn}={ms[0]*1e3:.0f}us")
         if dn == "full":
-            out[-1] += f" ({flops/ms[0]/1e9:.0f} TF, max|split-f32|={ms[1]:.2e})"
+            out[-1] += f" ({flops/ms[0]/1e9:.0f} TF, max|split-f32|={ms[1]:.2e}, stats rel {ms[2]:.1e})"
     print(f"{n:10s} M={B*H*W:8d} K={Cin*taps:5d} N={Cout:4d} " + "  ".join(out), flush=True)
