@@ -195,8 +195,9 @@ def main():
         split = eng.split_precision
         achieved = algo * 3.0 if split else algo
         peak = 2516.6 if split else 157.3
-        kernel = ("conv3x3_wide_kernel / conv_gemm_kernel (3x3 implicit GEMM; split-fp16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per K=16, "
-                  "fp32 accumulate)" if split else "conv_gemm_kernel (3x3 implicit GEMM; v_mfma_f32_32x32x2_f32)")
+        kernel = ("conv3x3_wide_kernel (3 x v_mfma_f32_16x16x32_f16 per K=32) / conv_gemm_kernel (3 x v_mfma_f32_32x32x16_f16 per K=16): "
+                  "3x3 implicit GEMM, split-fp16 operands, fp32 accumulate" if split
+                  else "conv_gemm_kernel (3x3 implicit GEMM; v_mfma_f32_32x32x2_f32)")
         traffic = None      # HBM bytes per launch of the same kernel class, from the committed rocprofv3 PMC passes
         try:
             with open(os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")) as fh:
