@@ -121,6 +121,7 @@ __device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&
         }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
     const int L = a.L;
@@ -231,21 +232,25 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_h, q_h, acc_s, 0, 0, 0);
                 acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_h, q_l, acc_s, 0, 0, 0);
                 acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_l, q_h, acc_s, 0, 0, 0);
+                // scores in log2 units (x log2 e / 256 folded into one multiply): softmax through exp2 directly
                 float sc[16];
                 float mloc = -1e30f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    sc[r] = (key < L) ? acc_s[r] * (1.0f / 256.0f) : -1e30f;
+                    sc[r] = acc_s[r] * (1.44269504088896340736f / 256.0f);
+                    if (!FULL) {
+                        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (key >= L) sc[r] = -1e30f;
+                    }
                     mloc = fmaxf(mloc, sc[r]);
                 }
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
                 const float m_new = fmaxf(m, mloc);
-                const float alpha = sa_exp_neg(m - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m - m_new);
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    sc[r] = sa_exp_neg(sc[r] - m_new);
+                    sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new + 10.0f);      // p x 1024: the split's pre-scale, for free
                     psum += sc[r];
                 }
                 lsum = lsum * alpha + psum;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         _Float16 h, l;
-                        sa_split(sc[8 * s2 + j] * 1024.0f, h, l);
+                        sa_split(sc[8 * s2 + j], h, l);
                         p_h[j] = h; p_l[j] = l;
                     }
                     const _Float16* vr_h = Vhi + li * VROW + kb * 32 + 16 * s2 + 4 * kh;
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 }
             }
             lsum += __shfl_xor(lsum, 32, 64);
-            const float inv = 1.0f / (lsum * 16384.0f);        // p x1024, v x16
+            const float inv = 1.0f / (lsum * 16.0f);           // lsum carries the x1024 of p already; v x16
 
             // ---- out-proj: av^T += W_o[:, 16 head .. 16 head + 15] . o_head^T  (one k-step; o rows = registers 0..7) ----
             s_f16x8 o_h, o_l;
@@ -357,12 +362,16 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 4)) * sizeof(_Float16);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused64_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused64_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused64_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(sa_fused64_kernel, dim3(B), dim3(64 * nwave), lds, s, a);
+    if (L % 32 == 0) hipLaunchKernelGGL(sa_fused64_kernel<true>, dim3(B), dim3(64 * nwave), lds, s, a);
+    else hipLaunchKernelGGL(sa_fused64_kernel<false>, dim3(B), dim3(64 * nwave), lds, s, a);
     return hipGetLastError();
 }
 
