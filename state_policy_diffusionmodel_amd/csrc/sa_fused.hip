@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     const int L = a.L;
     const int nwave = blockDim.x >> 6;
     const int Lp = nwave * 32;
-    const int VROW = Lp + 4;                       // halfs per V^T row
+    const int VROW = Lp + 8;                       // halfs per V^T row (16-byte aligned rows, 4-bank skew between rows)
     _Float16* Khi = reinterpret_cast<_Float16*>(sa_smem);
     _Float16* Klo = Khi + (size_t)Lp * SA_KROW;
     _Float16* Vhi = Klo + (size_t)Lp * SA_KROW;    // [32][VROW], rows 16..31 stay zero
@@ -137,6 +137,9 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     const int li = lane & 31, kh = lane >> 5;
     const int b = blockIdx.x;
     const int t = wave * 32 + li;                  // this lane's token
+    // position of token t in a V^T row: inside each group of 16 keys the order is [0-3, 8-11, 4-7, 12-15] (bits 2 and 3
+    // swapped), which makes the 8 keys a lane half feeds to one P.V MFMA (4 kh + 0..3 and 8 + 4 kh + 0..3) contiguous
+    const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
     const int tc = min(t, L - 1);
     const float* xrow = a.x + ((size_t)b * L + tc) * SA_C;
 
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 _Float16 h, l;
                 sa_split(vt[8 * sub + j] * 16.0f, h, l);
                 const int dd = 8 * (j >> 2) + 4 * kh + (j & 3);
-                Vhi[dd * VROW + t] = h;
-                Vlo[dd * VROW + t] = l;
+                Vhi[dd * VROW + tp] = h;
+                Vlo[dd * VROW + tp] = l;
             }
             __syncthreads();
 
@@ -232,25 +235,28 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_h, q_h, acc_s, 0, 0, 0);
                 acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_h, q_l, acc_s, 0, 0, 0);
                 acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_l, q_h, acc_s, 0, 0, 0);
-                // scores in log2 units (x log2 e / 256 folded into one multiply): softmax through exp2 directly
+                // softmax through v_exp_f32 directly: p x 1024 = exp2(acc_s c + (10 - m)), c = log2(e) / 256 (undoes the
+                // 16 x 16 operand pre-scale), running max m kept in log2 units -- one max, one fma, one exp2 per score
+                constexpr float SC = 1.44269504088896340736f / 256.0f;
                 float sc[16];
-                float mloc = -1e30f;
+                float mraw = -3.0e38f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    sc[r] = acc_s[r] * (1.44269504088896340736f / 256.0f);
+                    sc[r] = acc_s[r];
                     if (!FULL) {
                         const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                        if (key >= L) sc[r] = -1e30f;
+                        if (key >= L) sc[r] = -3.0e38f;
                     }
-                    mloc = fmaxf(mloc, sc[r]);
+                    mraw = fmaxf(mraw, sc[r]);
                 }
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                const float m_new = fmaxf(m, mloc);
+                mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+                const float m_new = fmaxf(m, mraw * SC);
                 const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                const float off = 10.0f - m_new;
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new + 10.0f);      // p x 1024: the split's pre-scale, for free
+                    sc[r] = __builtin_amdgcn_exp2f(__fmaf_rn(sc[r], SC, off));
                     psum += sc[r];
                 }
                 lsum = lsum * alpha + psum;
@@ -266,12 +272,8 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                         sa_split(sc[8 * s2 + j], h, l);
                         p_h[j] = h; p_l[j] = l;
                     }
-                    const _Float16* vr_h = Vhi + li * VROW + kb * 32 + 16 * s2 + 4 * kh;
-                    const _Float16* vr_l = Vlo + li * VROW + kb * 32 + 16 * s2 + 4 * kh;
-                    const s_f16x4 vh0 = *reinterpret_cast<const s_f16x4*>(vr_h), vh1 = *reinterpret_cast<const s_f16x4*>(vr_h + 8);
-                    const s_f16x4 vl0 = *reinterpret_cast<const s_f16x4*>(vr_l), vl1 = *reinterpret_cast<const s_f16x4*>(vr_l + 8);
-                    const s_f16x8 v_h = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
-                    const s_f16x8 v_l = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+                    const s_f16x8 v_h = *reinterpret_cast<const s_f16x8*>(Vhi + li * VROW + kb * 32 + 16 * s2 + 8 * kh);
+                    const s_f16x8 v_l = *reinterpret_cast<const s_f16x8*>(Vlo + li * VROW + kb * 32 + 16 * s2 + 8 * kh);
                     acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_h, acc_o, 0, 0, 0);
                     acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_l, acc_o, 0, 0, 0);
                     acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h, acc_o, 0, 0, 0);
@@ -359,7 +361,7 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     a.bqkv = bqkv; a.bo = bo; a.b1 = b1; a.b2 = b2;
     const int nwave = (L + 31) / 32;
     const int Lp = nwave * 32;
-    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 4)) * sizeof(_Float16);
+    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8)) * sizeof(_Float16);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused64_kernel<true>),
