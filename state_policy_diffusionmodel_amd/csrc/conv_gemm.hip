@@ -741,8 +741,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
             return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 1, 1>(a, g, s);
         }
         if (g.m_tile == 512) return launch_cfg<true, PREC_SPLIT, 8, 1, 2, 2, 3>(a, g, s);
+        if (conv_wide_supported(a, g)) return launch_conv_wide(a, g, s);          // conv_wide.hip (256- or 128-row tiles)
         if (g.m_tile == 256) {
-            if (conv_wide_supported(a, g)) return launch_conv_wide(a, g, s);      // conv_wide.hip: 4 waves x 128x64, 2 workgroups / CU
             if (uses_w2(a, g)) {   // level-2 maps: zero-tap skipping
                 if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3, true>(a, g, s);
                 return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3, true>(a, g, s);

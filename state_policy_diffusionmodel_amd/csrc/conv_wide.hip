@@ -68,19 +68,23 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
     return v;
 }
 
-template <int NT, int PRO, bool W2>
+template <int NT, int PRO, bool W2, int RT>
 __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS, const int stagger) {
     constexpr int WM = 2, WN = 2;
-    constexpr int RT = 8, CT = 2 * NT;                  // 16-row / 16-column tiles of a wave's 128 x (32 NT) strip
+    constexpr int CT = 2 * NT;                          // RT 16-row x CT 16-column tiles per wave (RT = 8: 128-row strip;
+                                                        // RT = 4: 64 rows -- 128-row workgroup tiles for small / coarse layers)
+    constexpr int RW = RT * 16;                         // rows per wave
     constexpr int NTHR = 256;
     constexpr int RP = NTHR / 8;
-    constexpr int M_T = 256, N_T = WN * NT * 32;
+    constexpr int M_T = WM * RW, N_T = WN * NT * 32;
     constexpr int APASS = (M_T + 18 + RP - 1) / RP;
     constexpr int FAR = W2 ? 4 : 3;                     // A-fragment ring (row tiles)
     constexpr int FBR = (NT == 2) ? 2 : 3;              // B-fragment ring (phases)
     constexpr int PH = 3 * NT;                          // phases per kernel row (generic layout)
-    static_assert(APASS <= 12, "sample-index packing: 5 bits per pass in 64");
+    constexpr int BB = (APASS <= 10) ? 6 : 5;           // bits per staging pass of the packed sample index
+    static_assert(APASS * BB <= 64, "sample-index packing");
     static_assert(!W2 || NT == 2, "the width-2 variant exists for 128-wide tiles");
+    static_assert(RT == 8 || (RT == 4 && NT == 2 && !W2), "64-row waves only in the tap-pair loop");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
         const bool v = (q < QA) && (m >= 0) && (m < M);
         if (v) {
             avalid |= 1u << p;
-            if (pro) abidx |= (unsigned long long)(m / HW - bh_first) << (5 * p);
+            if (pro) abidx |= (unsigned long long)(m / HW - bh_first) << (BB * p);
         }
     }
     const float* abase = a.src + c4 * 4;
@@ -164,12 +168,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     //      The 9 tap-validity bits of each of the 8 tiles are packed three tiles to a register. ----
 #define WIDE_ROWOFF(rt_) (W2 ? (((rt_) >> 1) * 32 + ((rt_) & 1)) : (rt_) * 16)
     const int rowlane = W2 ? 2 * l16 : l16;
-    const int aoff0 = (wm * 128 + rowlane + halo) * LDK + kg * 4;
+    const int aoff0 = (wm * RW + rowlane + halo) * LDK + kg * 4;
     const int zoff = QA * LDK + kg * 4;
-    unsigned am[3] = {0u, 0u, 0u};
+    unsigned am[(RT + 2) / 3] = {};
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const int m = m0 + wm * 128 + WIDE_ROWOFF(rt) + rowlane;
+        const int m = m0 + wm * RW + WIDE_ROWOFF(rt) + rowlane;
         unsigned mask = 0u;
         if (m < M) {
             const int p = m % HW;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                      \
             f32x4 v_ = areg[p_];                                                                     \
             if (pro) {                                                                               \
-                const int bi_ = (int)((abidx >> (5 * p_)) & 31ull);                                  \
+                const int bi_ = (int)((abidx >> (BB * p_)) & ((1ull << BB) - 1));                                  \
                 const float rs_ = srstd[bi_], mu_ = smean[bi_];                                      \
                 v_.x = (v_.x - mu_) * (rs_ * g4r.x) + b4r.x;                                         \
                 v_.y = (v_.y - mu_) * (rs_ * g4r.y) + b4r.y;                                         \
@@ -288,29 +292,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
             fat[slot_][0] = *reinterpret_cast<const f16x8*>(Abuf + o_);                              \
             fat[slot_][1] = *reinterpret_cast<const f16x8*>(Abuf + o_ + 16);                         \
         }
-#define TAP_SHIFT(tap_) ((((tap_) / 3 - 1) * W + ((tap_) - ((tap_) / 3) * 3 - 1)) * LDK)
-        const int ntaps = nchunks * 9;
+        // taps == 9: tap = 3 (dh + 1) + (dw + 1); taps == 3 (W == 1 maps, centre column only): tap = dh + 1, mask bit 3 tap + 1
+        const int TAPS = a.taps;
+        const bool t3 = (TAPS == 3);
+#define TAP_SHIFT(tap_) (t3 ? ((tap_) - 1) * W * LDK : (((tap_) / 3 - 1) * W + ((tap_) - ((tap_) / 3) * 3 - 1)) * LDK)
+#define TAP_BIT(tap_) (t3 ? 3 * (tap_) + 1 : (tap_))
+        const int ntaps = nchunks * TAPS;
         TAP_LOAD_B(0, 0, 0)
         WIDE_LOAD_A(0)
         WIDE_STAGE_A()
         __syncthreads();
         WIDE_STAMP(2)
-        TAP_LOAD_FA(0, 0, TAP_SHIFT(0), 0)
+        TAP_LOAD_FA(0, TAP_BIT(0), TAP_SHIFT(0), 0)
         int chunk = 0, tap = 0;
         for (int tt = 0; tt < ntaps; tt += 2) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 int ntap = tap + 1, nchunk = chunk;
-                if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
+                if (ntap == TAPS) { ntap = 0; nchunk = chunk + 1; }
                 const bool have_next = (tt + half + 1 < ntaps);
                 const bool next_A = have_next && (ntap == 0);
                 // unconditional prefetch (the last tap re-reads its own weights): see the header
                 TAP_LOAD_B(1 - half, (have_next ? nchunk : chunk), (have_next ? ntap : tap))
-                const int sh = TAP_SHIFT(tap), nsh = TAP_SHIFT(ntap);
+                const int sh = TAP_SHIFT(tap), nsh = TAP_SHIFT(ntap), tb = TAP_BIT(tap), ntb = TAP_BIT(ntap);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    if (rt + 1 < RT) { TAP_LOAD_FA((rt + 1) & 1, tap, sh, rt + 1) }
-                    else if (have_next && !next_A) { TAP_LOAD_FA(0, ntap, nsh, 0) }
+                    if (rt + 1 < RT) { TAP_LOAD_FA((rt + 1) & 1, tb, sh, rt + 1) }
+                    else if (have_next && !next_A) { TAP_LOAD_FA(0, ntb, nsh, 0) }
                     __builtin_amdgcn_sched_barrier(0);
                     if (!dbg_no_mfma) {
 #pragma unroll
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
                     __syncthreads();                // every wave is done reading the slab of this chunk
                     WIDE_STAGE_A()
                     __syncthreads();
-                    TAP_LOAD_FA(0, 0, TAP_SHIFT(0), 0)
+                    TAP_LOAD_FA(0, TAP_BIT(0), TAP_SHIFT(0), 0)
                 }
                 tap = ntap;
                 chunk = nchunk;
@@ -339,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 #undef TAP_LOAD_B
 #undef TAP_LOAD_FA
 #undef TAP_SHIFT
+#undef TAP_BIT
     } else if constexpr (!W2) {
         // phase ph of a kernel row: tap column ph / NT, column-tile pair ph % NT
         WIDE_LOAD_B(0, 0, 0, 0)
@@ -480,14 +489,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     // ---- epilogue: GroupNorm partial sums (fp32 per 4-row unit -> fp64 per sample, fixed order), then the
     //      tile through LDS in two halves so that every lane stores 16 bytes ----
     // accumulator layout: lane (l16, kg), register j of tile (rt, ct) = row 16 rt + 4 kg + j, column 16 ct + l16
-    constexpr int HROWS = WM * 64;                       // rows per half
+    constexpr int HROWS = M_T / 2;                       // rows per half (RW / 2 of each wave)
     float* otile = smem;                                 // [HROWS][N_T]
     float* srow = smem + HROWS * N_T;                    // [M_T / 4][WN][2]
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         // the lane's four registers are one 4-row unit (W2: rows 2 apart inside one 8-row block -> slot unit
         // 2 (block) + parity; a sample is still a contiguous run of HW / 4 slot units because HW % 8 == 0)
-        const int unit = wm * 32 + (W2 ? (rt >> 1) * 8 + 2 * kg + (rt & 1) : rt * 4 + kg);
+        const int unit = wm * (RW / 4) + (W2 ? (rt >> 1) * 8 + 2 * kg + (rt & 1) : rt * 4 + kg);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -509,8 +518,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int rt = 4 * h + rq;
+        for (int rq = 0; rq < RT / 2; ++rq) {
+            const int rt = (RT / 2) * h + rq;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int col_l = wn * NT * 32 + ct * 16 + l16;
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
                 for (int j = 0; j < 4; ++j) {
                     // row inside the wave's half (64 rows): W2 (rt>>1 - 2h) 32 + 2 (4 kg + j) + parity, else rq 16 + 4 kg + j
                     const int rw = W2 ? ((rt >> 1) - 2 * h) * 32 + 2 * (4 * kg + j) + (rt & 1) : rq * 16 + 4 * kg + j;
-                    otile[(wm * 64 + rw) * N_T + col_l] = acc[rt][ct][j];
+                    otile[(wm * (RW / 2) + rw) * N_T + col_l] = acc[rt][ct][j];
                 }
             }
         }
@@ -533,16 +542,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
                 // one lane per unit, fp64 butterfly inside each sample's (aligned, power-of-two) lane segment:
                 // fixed order, position-independent -> deterministic and identical for every sample
                 if (wave == 0) {
-                    const int u = lane;
-                    double d1 = (double)srow[(u * WN) * 2] + (double)srow[(u * WN + 1) * 2];
-                    double d2 = (double)srow[(u * WN) * 2 + 1] + (double)srow[(u * WN + 1) * 2 + 1];
-                    const int seg = whole ? 64 : ups;
+                    constexpr int NU = M_T / 4;                        // units of this tile: one lane each
+                    const int u = lane, uc = min(lane, NU - 1);
+                    double d1 = (double)srow[(uc * WN) * 2] + (double)srow[(uc * WN + 1) * 2];
+                    double d2 = (double)srow[(uc * WN) * 2 + 1] + (double)srow[(uc * WN + 1) * 2 + 1];
+                    const int seg = whole ? NU : ups;
                     for (int o = 1; o < seg; o <<= 1) {
                         d1 += __shfl_xor(d1, o, 64);
                         d2 += __shfl_xor(d2, o, 64);
                     }
                     const int row = t_lo + 4 * u;
-                    if ((u & (seg - 1)) == 0 && row < t_hi) {
+                    if (u < NU && (u & (seg - 1)) == 0 && row < t_hi) {
                         const int b = row / HW;
                         const int slot = (mtile - (b * HW) / M_T) * n_ntiles + ntile;
                         double* o = a.epi_stats + ((size_t)b * epi_slots + slot) * 2;
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 #pragma unroll 4
         for (int p = 0; p < HROWS / RPP; ++p) {
             const int lr = p * RPP + r0;
-            const int row = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+            const int row = m0 + (lr / (RW / 2)) * RW + h * (RW / 2) + lr % (RW / 2);
             if (row < M) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(otile + lr * N_T + c4o * 4);
                 *reinterpret_cast<f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4o * 4) = v;
@@ -585,18 +595,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 #undef WIDE_ROWOFF
 }
 
-template <int NT, int PRO, bool W2 = false>
+template <int NT, int PRO, bool W2 = false, int RT = 8>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
-    constexpr int M_T = 256, N_T = 64 * NT, NTHR = 256;
+    constexpr int M_T = 2 * RT * 16, N_T = 64 * NT, NTHR = 256;
+    constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 10) ? 64 : 32;
     const int halo = a.W + 1;
     const int QA = M_T + 2 * halo;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
-    if (NS > 32 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
+    if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     size_t lds = (size_t)((QA + 2) * LDK + 2 * NS) * sizeof(float);
-    lds = std::max(lds, (size_t)(128 * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
+    lds = std::max(lds, (size_t)((M_T / 2) * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
     if (const char* pad = getenv("SPDM_WIDE_LDSPAD")) lds += (size_t)atoi(pad);      // experiment: force one workgroup per CU
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<NT, PRO, W2>;
+    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -605,21 +616,30 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
         attr_set = true;
     }
     const int n_mtiles = (a.M + M_T - 1) / M_T;
-        static const int stagger = getenv("SPDM_WIDE_STAGGER") ? atoi(getenv("SPDM_WIDE_STAGGER")) : 0;
+    static const int stagger = getenv("SPDM_WIDE_STAGGER") ? atoi(getenv("SPDM_WIDE_STAGGER")) : 0;
     hipLaunchKernelGGL(kern, dim3(n_mtiles * g.n_tiles), dim3(NTHR), lds, s, a, g.slots, NS, stagger);
     return hipGetLastError();
 }
 
 }  // namespace
 
-static bool wide_w2(const GemmArgs& a) { return a.W == 2 && getenv("SPDM_NO_W2") == nullptr; }
+static bool wide_w2(const GemmArgs& a) { return a.W == 2 && a.taps == 9 && getenv("SPDM_NO_W2") == nullptr; }
 
+// Which layers run here: split-precision 3x3 convs (and the 3x1 convs of the W == 1 level) with GroupNorm-statistics
+// epilogue whose tiling (gemm_geometry) is 256 x {128, 64} -- or 128 x 128 (small batches, coarse levels), where the
+// workgroup is 4 waves x (64 x 64).
 bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
-    const bool ok = a.split && a.wgt_frag != nullptr && a.taps == 9 && g.m_tile == 256 && (g.n_tile == 128 || g.n_tile == 64) &&
-                    a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 && a.M % a.HW == 0 && a.epi == EPI_STATS && a.row_stats == nullptr &&
-                    (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && a.K % CK == 0 &&
-                    (256 + 2 * (a.W + 1) - 1) / a.HW + 2 <= 32 && getenv("SPDM_NO_WIDE") == nullptr;
-    if (!ok) return false;
+    const bool common = a.split && a.wgt_frag != nullptr && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 && a.M % a.HW == 0 &&
+                        a.epi == EPI_STATS && a.row_stats == nullptr && a.K % CK == 0 &&
+                        (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && getenv("SPDM_NO_WIDE") == nullptr;
+    if (!common) return false;
+    const int nsmax = (g.m_tile == 128) ? 64 : 32;
+    if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > nsmax) return false;
+    if (g.m_tile == 128)            // small tiles: the tap-pair loop only (128-wide, taps walked in pairs)
+        return g.n_tile == 128 && (a.taps == 9 || (a.taps == 3 && a.W == 1)) && a.K % 64 == 0 && getenv("SPDM_NO_WIDE128") == nullptr;
+    if (g.m_tile != 256) return false;
+    if (a.taps == 3) return a.W == 1 && g.n_tile == 128 && a.K % 64 == 0;
+    if (a.taps != 9 || !(g.n_tile == 128 || g.n_tile == 64)) return false;
     // width-2 maps: only with the zero-tap skipping variant (otherwise conv_gemm.hip's W2 configuration does less work)
     if (wide_w2(a)) return g.n_tile == 128 && (a.HW & 7) == 0;
     if (g.n_tile == 128 && a.K % 64 != 0) return false;      // the 128-wide loop walks taps in pairs
@@ -628,6 +648,11 @@ bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
 
 hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     if (!conv_wide_supported(a, g)) return hipErrorInvalidValue;
+    if (g.m_tile == 128) {
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4>(a, g, s);
+        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN_GELU, false, 4>(a, g, s);
+    }
     if (wide_w2(a)) {
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, true>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, true>(a, g, s);

@@ -424,7 +424,7 @@ struct Loader {
         }
         c.w = upload(v);
         c.ws = (cin % 32 == 0) ? upload_split(v, cin) : nullptr;
-        if (taps == 9 && cin % 32 == 0 && cout % 64 == 0) c.wf = upload(frag_order_weights(split_format(v), taps, cout, cin));
+        if (cin % 32 == 0 && cout % 64 == 0) c.wf = upload(frag_order_weights(split_format(v), taps, cout, cin));
         c.taps = taps; c.cin = cin; c.cout = cout;
         return c;
     }
@@ -1201,7 +1201,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
                 }
             }
             hw.swap(out);
-            if (taps == 9 && Cout % 64 == 0 && Cin % 32 == 0) {
+            if ((taps == 9 || taps == 3) && Cout % 64 == 0 && Cin % 32 == 0) {
                 const std::vector<float> fr = frag_order_weights(hw, taps, Cout, Cin);
                 HIP_TRY(hipMalloc((void**)&wfrag, nw * 4));
                 HIP_TRY(hipMemcpy(wfrag, fr.data(), nw * 4, hipMemcpyHostToDevice));

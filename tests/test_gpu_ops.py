@@ -52,7 +52,8 @@ def test_wide_conv_kernel_shapes_against_exact_fp32_path():
     """conv3x3_wide_kernel (conv_wide.hip: large-batch 3x3 convs of levels 0-2) against the exact fp32-MFMA kernel on
     the same synthetic data, outputs AND per-sample GroupNorm totals: 128- and 64-wide tiles, all three prologues, the
     width-2 zero-tap-skipping variant, ragged last tiles (M % 256 != 0), several samples per tile (HW = 128, 64, 32,
-    16), tiles inside one sample (HW = 512), and a sample length that is not a power of two (HW = 192: serial totals)."""
+    16, 4), tiles inside one sample (HW = 512), a sample length that is not a power of two (HW = 192: serial totals),
+    the 128-row-tile variant and the 3-tap (W == 1) convs."""
     from state_policy_diffusionmodel_amd import _lib
     lib = _lib.load()
     cases = [  # B, H, W, Cin, Cout, taps, pro, epi      (M / 256 * Cout / n_tile >= 192 selects the wide kernel)
@@ -61,6 +62,9 @@ def test_wide_conv_kernel_shapes_against_exact_fp32_path():
         (771, 16, 4, 128, 128, 9, 2, 0), (1543, 8, 4, 64, 256, 9, 1, 0),
         (200, 32, 8, 64, 64, 9, 2, 0), (387, 32, 8, 128, 64, 9, 1, 0), (1541, 16, 4, 64, 64, 9, 0, 0),
         (3083, 8, 2, 128, 128, 9, 2, 0), (1601, 8, 2, 256, 256, 9, 0, 0), (1600, 16, 2, 64, 128, 9, 1, 0),
+        # 128-row tiles (4 waves x 64 x 64): small batches / coarse levels, and the 3-tap convs of the W == 1 level
+        (110, 32, 8, 64, 128, 9, 2, 0), (437, 16, 4, 128, 128, 9, 0, 0), (1600, 8, 2, 128, 128, 9, 1, 0),
+        (4000, 4, 1, 256, 256, 3, 2, 0), (4093, 4, 1, 512, 256, 3, 1, 0), (7000, 4, 1, 256, 512, 3, 1, 0), (4096, 4, 1, 512, 512, 3, 0, 0),
     ]
     for B, H, W, Cin, Cout, taps, pro, epi in cases:
         ms = (ctypes.c_double * 3)()
