@@ -69,7 +69,7 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
 }
 
 template <int NT, int PRO, bool W2, int RT>
-__global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS, const int stagger) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS) {
     constexpr int WM = 2, WN = 2;
     constexpr int CT = 2 * NT;                          // RT 16-row x CT 16-column tiles per wave (RT = 8: 128-row strip;
                                                         // RT = 4: 64 rows -- 128-row workgroup tiles for small / coarse layers)
@@ -122,12 +122,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     constexpr bool dbg_no_mfma = false, dbg_no_wload = false;     // ablation knobs exist in diagnostic builds only
 #endif
     WIDE_STAMP(1)
-    // experiment knob (SPDM_WIDE_STAGGER, default 0; measured: no effect): start the workgroup in the CU's second
-    // wave slot late, once
-    if (stagger > 0 && bid < 2 * 256 && (__builtin_amdgcn_s_getreg(63492) & 1u)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(64);
-    }
     if (tid < LDK) Abuf[QA * LDK + tid] = 0.f;
 
     constexpr bool pro = (PRO != PRO_NONE);
@@ -605,7 +599,6 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     size_t lds = (size_t)((QA + 2) * LDK + 2 * NS) * sizeof(float);
     lds = std::max(lds, (size_t)((M_T / 2) * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
-    if (const char* pad = getenv("SPDM_WIDE_LDSPAD")) lds += (size_t)atoi(pad);      // experiment: force one workgroup per CU
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT>;
     static bool attr_set = false;
@@ -616,8 +609,7 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
         attr_set = true;
     }
     const int n_mtiles = (a.M + M_T - 1) / M_T;
-    static const int stagger = getenv("SPDM_WIDE_STAGGER") ? atoi(getenv("SPDM_WIDE_STAGGER")) : 0;
-    hipLaunchKernelGGL(kern, dim3(n_mtiles * g.n_tiles), dim3(NTHR), lds, s, a, g.slots, NS, stagger);
+    hipLaunchKernelGGL(kern, dim3(n_mtiles * g.n_tiles), dim3(NTHR), lds, s, a, g.slots, NS);
     return hipGetLastError();
 }
 
