@@ -22,6 +22,7 @@
 // the pre-scaled operand, three v_mfma_f32_32x32x16_f16, fp32 accumulate): activations x16, weights x128,
 // probabilities x1024.
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_utils.h"
 
@@ -81,6 +82,29 @@ __device__ __forceinline__ s_f32x16 sa_gemm_tile(const _Float16* __restrict__ Wh
     }
     return acc;
 }
+// same product with the weight rows staged in LDS (rows padded 128 -> 144 bytes: 32 rows x 16 bytes conflict-free)
+constexpr int SA_WROW = 72;          // halfs per staged weight row
+__device__ __forceinline__ s_f32x16 sa_gemm_tile_lds(const _Float16* Wh, const _Float16* Wl, int row0, int li, int kh,
+                                                      const s_f16x8 (&bh)[4], const s_f16x8 (&bl)[4], s_f32x16 acc) {
+    const _Float16* ph = Wh + (row0 + li) * SA_WROW + 8 * kh;
+    const _Float16* pl = Wl + (row0 + li) * SA_WROW + 8 * kh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const s_f16x8 ah = *reinterpret_cast<const s_f16x8*>(ph + 16 * ks);
+        const s_f16x8 al = *reinterpret_cast<const s_f16x8*>(pl + 16 * ks);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
+    }
+    return acc;
+}
+// cooperative copy of nrows weight rows (64 halfs each) global -> LDS rows dst_row0.. (16 bytes per thread per step)
+__device__ __forceinline__ void sa_stage_rows(_Float16* dst, int dst_row0, const _Float16* __restrict__ src, int nrows, int tid, int nthr) {
+    for (int i = tid; i < nrows * 8; i += nthr) {
+        const int r = i >> 3, c = i & 7;
+        *reinterpret_cast<s_f16x8*>(dst + (dst_row0 + r) * SA_WROW + 8 * c) = *reinterpret_cast<const s_f16x8*>(src + (size_t)r * SA_C + 8 * c);
+    }
+}
 // z[T][r] -> z * DESCALE + bias[feature]   (feature of register r in tile T: 32 T + (r&3) + 8 (r>>2) + 4 kh)
 __device__ __forceinline__ void sa_bias(s_f32x16& z, const float* __restrict__ bias, int T, int kh) {
 #pragma unroll
@@ -121,7 +145,10 @@ __device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&
         }
 }
 
-template <bool FULL>
+// WLDS: the workgroup stages the weight matrices in LDS once (256 + 128 rows, two phases) and every wave reads its A
+// fragments from there -- for the long-sequence block (8 waves per trajectory) this replaces 8 x 98 KB of per-wave
+// L2 reads, whose latency the 2 waves per SIMD could not hide (40 % of wave cycles parked), by one 98 KB copy.
+template <bool FULL, bool WLDS>
 __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
     const int L = a.L;
@@ -132,6 +159,8 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     _Float16* Klo = Khi + (size_t)Lp * SA_KROW;
     _Float16* Vhi = Klo + (size_t)Lp * SA_KROW;    // [32][VROW], rows 16..31 stay zero
     _Float16* Vlo = Vhi + (size_t)32 * VROW;
+    _Float16* Wsh = Vlo + (size_t)32 * VROW;       // WLDS: [256][SA_WROW] hi rows: phase A qkv 0..191, out-proj 192..255; phase B w1 0..63, w2 64..127
+    _Float16* Wsl = Wsh + (size_t)256 * SA_WROW;   //        [256][SA_WROW] lo rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
@@ -147,6 +176,14 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     for (int i = tid; i < 16 * VROW; i += blockDim.x) {
         Vhi[16 * VROW + i] = (_Float16)0.f;
         Vlo[16 * VROW + i] = (_Float16)0.f;
+    }
+
+    if (WLDS) {
+        sa_stage_rows(Wsh, 0, a.wqkv_h, 192, tid, blockDim.x);
+        sa_stage_rows(Wsl, 0, a.wqkv_l, 192, tid, blockDim.x);
+        sa_stage_rows(Wsh, 192, a.wo_h, 64, tid, blockDim.x);
+        sa_stage_rows(Wsl, 192, a.wo_l, 64, tid, blockDim.x);
+        __syncthreads();
     }
 
     // ---- x^T tiles of this token: register r of tile T = feature 32 T + (r&3) + 8 (r>>2) + 4 kh ----
@@ -179,9 +216,15 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         s_f32x16 qt, kt, vt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { qt[r] = 0.f; kt[r] = 0.f; vt[r] = 0.f; }
-        qt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 32 * p, li, kh, bh, bl, qt);
-        kt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 64 + 32 * p, li, kh, bh, bl, kt);
-        vt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 128 + 32 * p, li, kh, bh, bl, vt);
+        if (WLDS) {
+            qt = sa_gemm_tile_lds(Wsh, Wsl, 32 * p, li, kh, bh, bl, qt);
+            kt = sa_gemm_tile_lds(Wsh, Wsl, 64 + 32 * p, li, kh, bh, bl, kt);
+            vt = sa_gemm_tile_lds(Wsh, Wsl, 128 + 32 * p, li, kh, bh, bl, vt);
+        } else {
+            qt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 32 * p, li, kh, bh, bl, qt);
+            kt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 64 + 32 * p, li, kh, bh, bl, kt);
+            vt = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 128 + 32 * p, li, kh, bh, bl, vt);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const s_f32x4 bq = *reinterpret_cast<const s_f32x4*>(a.bqkv + 32 * p + 8 * g + 4 * kh);
@@ -292,8 +335,10 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             }
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
-                const s_f16x8 ah = *reinterpret_cast<const s_f16x8*>(a.wo_h + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
-                const s_f16x8 al = *reinterpret_cast<const s_f16x8*>(a.wo_l + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
+                const s_f16x8 ah = WLDS ? *reinterpret_cast<const s_f16x8*>(Wsh + (192 + 32 * T + li) * SA_WROW + 16 * head + 8 * kh)
+                                        : *reinterpret_cast<const s_f16x8*>(a.wo_h + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
+                const s_f16x8 al = WLDS ? *reinterpret_cast<const s_f16x8*>(Wsl + (192 + 32 * T + li) * SA_WROW + 16 * head + 8 * kh)
+                                        : *reinterpret_cast<const s_f16x8*>(a.wo_l + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, o_h, av[T], 0, 0, 0);
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, o_l, av[T], 0, 0, 0);
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, o_h, av[T], 0, 0, 0);
@@ -309,6 +354,14 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         for (int r = 0; r < 16; ++r) av[T][r] += xt[T][r];
     }
     // ---- feed-forward: LN -> W1 -> GELU -> W2 -> + av ----
+    if (WLDS) {                                     // phase B of the staged weights (every wave is past the out-proj reads)
+        __syncthreads();
+        sa_stage_rows(Wsh, 0, a.w1_h, 64, tid, blockDim.x);
+        sa_stage_rows(Wsl, 0, a.w1_l, 64, tid, blockDim.x);
+        sa_stage_rows(Wsh, 64, a.w2_h, 64, tid, blockDim.x);
+        sa_stage_rows(Wsl, 64, a.w2_l, 64, tid, blockDim.x);
+        __syncthreads();
+    }
     {
         s_f32x16 ln[2];
         sa_layernorm(av, ln, a.ln2_g, a.ln2_b, kh);
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
-        f[T] = sa_gemm_tile(a.w1_h, a.w1_l, 32 * T, li, kh, bh, bl, f[T]);
+        f[T] = WLDS ? sa_gemm_tile_lds(Wsh, Wsl, 32 * T, li, kh, bh, bl, f[T]) : sa_gemm_tile(a.w1_h, a.w1_l, 32 * T, li, kh, bh, bl, f[T]);
         sa_bias(f[T], a.b1, T, kh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[T][r] = gelu_erf(f[T][r]);
@@ -329,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
-        f[T] = sa_gemm_tile(a.w2_h, a.w2_l, 32 * T, li, kh, bh, bl, f[T]);
+        f[T] = WLDS ? sa_gemm_tile_lds(Wsh, Wsl, 64 + 32 * T, li, kh, bh, bl, f[T]) : sa_gemm_tile(a.w2_h, a.w2_l, 32 * T, li, kh, bh, bl, f[T]);
         sa_bias(f[T], a.b2, T, kh);
     }
     if (t < L) {
@@ -361,19 +414,24 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     a.bqkv = bqkv; a.bo = bo; a.b1 = b1; a.b2 = b2;
     const int nwave = (L + 31) / 32;
     const int Lp = nwave * 32;
-    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8)) * sizeof(_Float16);
+    const bool wlds = (nwave >= 4) && getenv("SPDM_SA_NO_WLDS") == nullptr;      // long sequences: weights staged in LDS
+    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused64_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused64_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) return e;
+    if (!attr) {
+        const void* ks[4] = {reinterpret_cast<const void*>(sa_fused64_kernel<true, true>), reinterpret_cast<const void*>(sa_fused64_kernel<true, false>),
+                             reinterpret_cast<const void*>(sa_fused64_kernel<false, true>), reinterpret_cast<const void*>(sa_fused64_kernel<false, false>)};
+        for (const void* k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+            if (e != hipSuccess) return e;
+        }
         attr = true;
     }
-    if (L % 32 == 0) hipLaunchKernelGGL(sa_fused64_kernel<true>, dim3(B), dim3(64 * nwave), lds, s, a);
-    else hipLaunchKernelGGL(sa_fused64_kernel<false>, dim3(B), dim3(64 * nwave), lds, s, a);
+    const bool full = (L % 32 == 0);
+    if (full && wlds) hipLaunchKernelGGL((sa_fused64_kernel<true, true>), dim3(B), dim3(64 * nwave), lds, s, a);
+    else if (full) hipLaunchKernelGGL((sa_fused64_kernel<true, false>), dim3(B), dim3(64 * nwave), lds, s, a);
+    else if (wlds) hipLaunchKernelGGL((sa_fused64_kernel<false, true>), dim3(B), dim3(64 * nwave), lds, s, a);
+    else hipLaunchKernelGGL((sa_fused64_kernel<false, false>), dim3(B), dim3(64 * nwave), lds, s, a);
     return hipGetLastError();
 }
 
