@@ -1175,7 +1175,8 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     HIP_TRY(hipMalloc((void**)&dst, ndst * 4));
     HIP_TRY(hipMalloc((void**)&resid, ndst * 4));
     HIP_TRY(hipMalloc((void**)&gb, (size_t)(Cin + Cout) * 2 * 4));
-    HIP_TRY(hipMalloc((void**)&st_in, (size_t)B * 2 * 8));
+    const bool row_ln = (taps == 1 && pro != 0);           // Linear with a LayerNorm prologue: statistics per ROW
+    HIP_TRY(hipMalloc((void**)&st_in, (size_t)(row_ln ? M : B) * 2 * 8));
     HIP_TRY(hipMalloc((void**)&st_out, (size_t)B * g.slots * 2 * 8));
     HIP_TRY(hipMemset(st_out, 0, (size_t)B * g.slots * 2 * 8));
     const GemmGeom g2 = gemm_geometry(M, Cout, HW, taps, 0);
@@ -1207,8 +1208,8 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
                 HIP_TRY(hipMemcpy(wfrag, fr.data(), nw * 4, hipMemcpyHostToDevice));
             }
         }
-        std::vector<double> hst((size_t)B * 2);
-        for (int b = 0; b < B; ++b) { hst[2 * b] = 0.0; hst[2 * b + 1] = (double)Cin * HW / 3.0; }
+        std::vector<double> hst((size_t)(row_ln ? M : B) * 2);
+        for (size_t b = 0; b < hst.size() / 2; ++b) { hst[2 * b] = 0.0; hst[2 * b + 1] = (double)Cin * (row_ln ? 1 : HW) / 3.0; }
         HIP_TRY(hipMemcpy(src, hsrc.data(), nsrc * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(wgt, hw.data(), nw * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(gb, hgb.data(), hgb.size() * 4, hipMemcpyHostToDevice));
@@ -1218,9 +1219,11 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     GemmArgs a{};
     a.src = src; a.src_ld = Cin; a.wgt = wgt; a.wgt_frag = wfrag; a.split = split; a.dst = dst; a.dst_ld = Cout;
     a.M = M; a.K = Cin; a.N = Cout; a.taps = taps; a.H = H; a.W = W; a.HW = HW;
+    if (row_ln) { a.H = 1; a.W = 1; a.HW = 1; }             // like Ctx::linear: every row is its own LayerNorm "sample"
     a.pro = pro;
-    a.pro_stats.p = st_in; a.pro_stats.slots = 1; a.pro_stats.m_tile = HW; a.pro_stats.n_tiles = 1; a.pro_stats.HW = HW;
-    a.pro_stats.inv_count = 1.0 / ((double)Cin * HW);
+    a.pro_stats.p = st_in; a.pro_stats.slots = 1; a.pro_stats.m_tile = row_ln ? (1 << 30) : HW; a.pro_stats.n_tiles = 1;
+    a.pro_stats.HW = row_ln ? 1 : HW;
+    a.pro_stats.inv_count = 1.0 / ((double)Cin * (row_ln ? 1 : HW));
     a.pro_gamma = gb; a.pro_beta = gb + Cin;
     a.epi = epi; a.epi_stats = st_out; a.bias = gb + 2 * Cin; a.resid = resid; a.resid_ld = Cout;
     a.debug = debug;

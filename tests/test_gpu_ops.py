@@ -71,3 +71,19 @@ def test_wide_conv_kernel_shapes_against_exact_fp32_path():
         _lib.check(lib.spdm_bench_gemm(0, B, H, W, Cin, Cout, taps, pro, epi, 1, 1, 0, ms), "spdm_bench_gemm")
         assert 0.0 <= ms[1] <= 5e-5, ((B, H, W, Cin, Cout, taps, pro, epi), ms[1])
         assert 0.0 <= ms[2] <= 1e-5, ((B, H, W, Cin, Cout, taps, pro, epi), "GroupNorm totals", ms[2])
+
+
+def test_linear_gemms_of_the_attention_chains_against_exact_fp32_path():
+    """The Linear layers of the attention chains at large batch (conv_gemm_kernel, 1 tap, 128-wide tiles) against the
+    exact fp32-MFMA GEMM: K = 128 / 256, N = 128..768, LayerNorm prologue (per-row statistics), bias / GELU / residual
+    epilogues, ragged last tile."""
+    from state_policy_diffusionmodel_amd import _lib
+    lib = _lib.load()
+    cases = [  # B, H, W, Cin, Cout, taps, pro, epi   (M / 128 * Cout / 128 >= 192 selects 128-wide tiles)
+        (400, 16, 4, 128, 384, 1, 1, 1), (401, 16, 4, 128, 128, 1, 0, 3), (777, 8, 4, 128, 128, 1, 1, 2),
+        (1025, 8, 2, 256, 768, 1, 1, 1), (1600, 8, 2, 256, 256, 1, 0, 3), (6200, 4, 1, 256, 256, 1, 1, 2),
+    ]
+    for B, H, W, Cin, Cout, taps, pro, epi in cases:
+        ms = (ctypes.c_double * 3)()
+        _lib.check(lib.spdm_bench_gemm(0, B, H, W, Cin, Cout, taps, pro, epi, 1, 1, 0, ms), "spdm_bench_gemm")
+        assert 0.0 <= ms[1] <= 5e-5, ((B, H, W, Cin, Cout, taps, pro, epi), ms[1])

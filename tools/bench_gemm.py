@@ -19,7 +19,8 @@ SHAPES = {  # name: (H, W, Cin, Cout, taps, pro, epi)
     "up1.dc2a": (8, 2, 512, 128, 9, 1, 0), "down2.b": (8, 2, 128, 128, 9, 2, 0), "down2.c": (8, 2, 128, 256, 9, 1, 0),
     "bot2a": (4, 1, 512, 512, 3, 1, 0), "down3": (4, 1, 256, 256, 3, 2, 0),
     "sa6.qkv": (32, 8, 64, 192, 1, 0, 1), "sa6.out": (32, 8, 64, 64, 1, 0, 3), "sa6.ff1": (32, 8, 64, 64, 1, 0, 2),
-    "sa1.qkv": (16, 4, 128, 384, 1, 0, 1),
+    "sa1.qkv": (16, 4, 128, 384, 1, 1, 1), "sa1.out": (16, 4, 128, 128, 1, 0, 3), "sa1.ff1": (16, 4, 128, 128, 1, 1, 2),
+    "sa2.qkv": (8, 2, 256, 768, 1, 1, 1), "sa2.out": (8, 2, 256, 256, 1, 0, 3), "sa4.ff2": (8, 2, 128, 128, 1, 0, 3),
 }
 DBG = {"full": 0, "stamp": 128, "pp": 64, "pp+stamp": 192, "noMFMA": 1, "noWload": 2, "noGELU": 4, "noStore": 8, "noAload": 16, "noMFMA+noW": 3, "noW+stamp": 130, "noMFMA+noW+noA+noSt": 27}
 split = 0 if "--f32" in sys.argv else 1
