@@ -68,9 +68,9 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
     return v;
 }
 
-template <int NT, int PRO, bool W2, int RT>
+template <int NT, int PRO, bool W2, int RT, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS) {
-    constexpr int WM = 2, WN = 2;
+    constexpr int WM = 4 / WN;                          // 4 waves: 2 x 2, or 4 x 1 for 64-wide outputs (each wave 64 rows x 64 columns)
     constexpr int CT = 2 * NT;                          // RT 16-row x CT 16-column tiles per wave (RT = 8: 128-row strip;
                                                         // RT = 4: 64 rows -- 128-row workgroup tiles for small / coarse layers)
     constexpr int RW = RT * 16;                         // rows per wave
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     static_assert(APASS * BB <= 64, "sample-index packing");
     static_assert(!W2 || NT == 2, "the width-2 variant exists for 128-wide tiles");
     static_assert(RT == 8 || (RT == 4 && NT == 2 && !W2), "64-row waves only in the tap-pair loop");
+    static_assert(WN == 2 || (WN == 1 && RT == 4), "the 4 x 1 wave arrangement uses 64-row waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -538,8 +539,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
                 if (wave == 0) {
                     constexpr int NU = M_T / 4;                        // units of this tile: one lane each
                     const int u = lane, uc = min(lane, NU - 1);
-                    double d1 = (double)srow[(uc * WN) * 2] + (double)srow[(uc * WN + 1) * 2];
-                    double d2 = (double)srow[(uc * WN) * 2 + 1] + (double)srow[(uc * WN + 1) * 2 + 1];
+                    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                    for (int w2 = 0; w2 < WN; ++w2) {
+                        d1 += (double)srow[(uc * WN + w2) * 2];
+                        d2 += (double)srow[(uc * WN + w2) * 2 + 1];
+                    }
                     const int seg = whole ? NU : ups;
                     for (int o = 1; o < seg; o <<= 1) {
                         d1 += __shfl_xor(d1, o, 64);
@@ -589,18 +594,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 #undef WIDE_ROWOFF
 }
 
-template <int NT, int PRO, bool W2 = false, int RT = 8>
+template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
-    constexpr int M_T = 2 * RT * 16, N_T = 64 * NT, NTHR = 256;
+    constexpr int M_T = (4 / WN) * RT * 16, N_T = WN * 32 * NT, NTHR = 256;
     constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 10) ? 64 : 32;
     const int halo = a.W + 1;
     const int QA = M_T + 2 * halo;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     size_t lds = (size_t)((QA + 2) * LDK + 2 * NS) * sizeof(float);
-    lds = std::max(lds, (size_t)((M_T / 2) * N_T + (M_T / 4) * 2 * 2) * sizeof(float));
+    lds = std::max(lds, (size_t)((M_T / 2) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT>;
+    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -654,6 +659,13 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN>(a, g, s);
         return launch_wide_cfg<2, PRO_GN_GELU>(a, g, s);
+    }
+    // 64-wide outputs: four waves along M, each 64 rows x all 64 columns (an A fragment feeds 12 MFMAs, as on 128-wide
+    // tiles), tap-pair loop; K % 64 != 0 keeps the 2 x 2 arrangement with 128 x 32 waves
+    if (a.K % 64 == 0 && getenv("SPDM_WIDE_N64_2X2") == nullptr) {
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 1>(a, g, s);
+        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 1>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 1>(a, g, s);
     }
     if (a.pro == PRO_NONE) return launch_wide_cfg<1, PRO_NONE>(a, g, s);
     if (a.pro == PRO_GN) return launch_wide_cfg<1, PRO_GN>(a, g, s);
