@@ -14,25 +14,46 @@
 
 namespace spdm {
 
+// exp(x) for x <= 0 through v_exp_f32 with a compensated argument (~1e-7 relative error up to |x| ~ 80)
+__device__ __forceinline__ float att_exp_neg(float x) {
+    const float t = x * 1.44269504f;
+    const float tl = __fmaf_rn(x, 1.44269504f, -t) + x * 1.925963033e-8f;
+    return __builtin_amdgcn_exp2f(t) * (1.0f + tl * 0.69314718f);
+}
+
+// Short sequences (L = 4..32 tokens: the coarse levels) pack G = 64 / L (sample, head) pairs into one wave, so that
+// every lane owns a query; longer ones run one pair per workgroup.  K / V rows are padded by 4 floats and the groups
+// are skewed by 4 banks so that the G distinct rows a wave instruction reads never share a bank.
 template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                        int L, int C, int heads) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // K [L][D], V [L][D]
-    float* Ks = sm;
-    float* Vs = sm + (size_t)L * D;
-    const int bh = blockIdx.x, b = bh / heads, hd = bh - b * heads;
+                                                        int L, int C, int heads, int G, int GS, int npairs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // per group: K [L][D + 4], V [L][D + 4]
+    constexpr int RS = D + 4;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const size_t ld = (size_t)3 * C;
-    const float* base = qkv + (size_t)b * L * ld + hd * D;
     constexpr int D4 = D / 4;
-    for (int i = tid; i < L * D4; i += nthr) {
-        const int j = i / D4, k4 = i - j * D4;
-        *reinterpret_cast<float4*>(Ks + j * D + k4 * 4) = *reinterpret_cast<const float4*>(base + j * ld + C + k4 * 4);
-        *reinterpret_cast<float4*>(Vs + j * D + k4 * 4) = *reinterpret_cast<const float4*>(base + j * ld + 2 * C + k4 * 4);
+    const int pair0 = blockIdx.x * G;
+    float* Ksm = sm;
+    float* Vsm = sm + (size_t)G * GS;
+    for (int i = tid; i < G * L * D4; i += nthr) {
+        const int g = i / (L * D4), r = i - g * (L * D4);
+        const int j = r / D4, k4 = r - j * D4;
+        const int bh = min(pair0 + g, npairs - 1), b = bh / heads, hd = bh - b * heads;
+        const float* base = qkv + (size_t)b * L * ld + hd * D;
+        *reinterpret_cast<float4*>(Ksm + g * GS + j * RS + k4 * 4) = *reinterpret_cast<const float4*>(base + j * ld + C + k4 * 4);
+        *reinterpret_cast<float4*>(Vsm + g * GS + j * RS + k4 * 4) = *reinterpret_cast<const float4*>(base + j * ld + 2 * C + k4 * 4);
     }
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)D);
-    for (int qi = tid; qi < L; qi += nthr) {
+    const int per = (G > 1) ? L : nthr;                  // queries handled side by side per group
+    const int g = (G > 1) ? tid / L : 0;
+    const int bh = pair0 + g;
+    if (g >= G || bh >= npairs) return;
+    const int b = bh / heads, hd = bh - b * heads;
+    const float* base = qkv + (size_t)b * L * ld + hd * D;
+    const float* Ks = Ksm + g * GS;
+    const float* Vs = Vsm + g * GS;
+    for (int qi = (G > 1) ? tid - g * L : tid; qi < L; qi += per) {
         float q[D], o[D];
 #pragma unroll
         for (int k4 = 0; k4 < D4; ++k4) {
@@ -41,9 +62,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) o[k] = 0.f;
-        float m = -INFINITY, l = 0.f;
+        float m = -1e30f, l = 0.f;
         for (int j = 0; j < L; ++j) {
-            const float* kr = Ks + j * D;
+            const float* kr = Ks + j * RS;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int k = 0; k < D; k += 4) {
@@ -52,10 +73,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             }
             const float sc = (s0 + s1) + (s2 + s3);
             const float mn = fmaxf(m, sc);
-            const float alpha = expf(m - mn);      // exp(-inf) = 0 on the first key
-            const float p = expf(sc - mn);
+            const float alpha = att_exp_neg(m - mn);     // first key: exp(-1e30) = 0
+            const float p = att_exp_neg(sc - mn);
             l = l * alpha + p;
-            const float* vr = Vs + j * D;
+            const float* vr = Vs + j * RS;
 #pragma unroll
             for (int k = 0; k < D; k += 4) {
                 const float4 vv = *reinterpret_cast<const float4*>(vr + k);
@@ -76,11 +97,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 hipError_t launch_attention(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s) {
     if (B <= 0 || L <= 0 || heads <= 0 || C % heads != 0) return hipErrorInvalidValue;
     const int d = C / heads;
-    const size_t lds = (size_t)2 * L * d * sizeof(float);
+    const int npairs = B * heads;
+    const int G = (L <= 32 && (L & (L - 1)) == 0) ? 64 / L : 1;          // (sample, head) pairs per workgroup
+    const int RS = d + 4;
+    const int GS = L * RS + ((4 - (L * RS) % 64 + 64) % 64);               // group stride = 4 (mod 64 banks)
+    const size_t lds = (size_t)2 * G * GS * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     int threads = ((L + 63) / 64) * 64;
     if (threads > 256) threads = 256;
-    const dim3 grid(B * heads), block(threads);
+    if (G > 1) threads = 64;
+    const dim3 grid((npairs + G - 1) / G), block(threads);
 #define SPDM_ATT(DD)                                                                                          \
     {                                                                                                         \
         auto kern = attention_kernel<DD>;                                                                     \
@@ -89,7 +115,7 @@ hipError_t launch_attention(const float* qkv, float* out, int B, int L, int C, i
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); \
             if (e != hipSuccess) return e;                                                                    \
         }                                                                                                     \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, qkv, out, L, C, heads);                                 \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, qkv, out, L, C, heads, G, GS, npairs);                  \
     }
     switch (d) {
         case 16: SPDM_ATT(16) break;
