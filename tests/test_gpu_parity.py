@@ -247,12 +247,15 @@ def test_device_philox_stream_matches_oracle_and_is_shard_invariant():
         eng.close()
 
 
-def test_full_size_batch_properties():
-    """BASELINE.json's batch (4096, horizon 32): too large for the CPU oracle in seconds, so check
-    size-independent properties: each trajectory of the big batch equals the same trajectory run in a
-    small batch (the oracle-checked regime), inpainted rows are exact, output finite."""
+@pytest.mark.parametrize("B,H,D", [(4096, 32, 3), (1024, 64, 6), (1500, 16, 3)],
+                         ids=["config4_b4096_h32d3", "config5_geometry_b1024_h64d6", "b1500_h16d3"])
+def test_full_size_batch_properties(B, H, D):
+    """BASELINE.json's batches (4096 x horizon 32; horizon 64 x state_dim 6; plus a ragged one at horizon 16): too
+    large for the CPU oracle in seconds, so check size-independent properties: each trajectory of the big batch
+    (large-batch kernels: conv3x3_wide_kernel in all its variants) equals the same trajectory run in a small batch
+    (the oracle-checked regime), inpainted rows are exact, output finite."""
     from state_policy_diffusionmodel_amd.schedulers import DDPMScheduler
-    B, H, D, cd, T, N = 4096, 32, 3, 1350, 1000, 2
+    cd, T, N = 1350, 1000, 2
     sd = weights(cd, 0)
     g = torch.Generator().manual_seed(2)
     cond = torch.randn(B, 1, 10, 135, generator=g).cuda()
@@ -268,7 +271,7 @@ def test_full_size_batch_properties():
         big = eng.sample_result().cpu()
         assert bool(torch.isfinite(big).all())
         assert torch.equal(big[:, :, :1, :], inpaint.cpu())
-        idx = [0, 1, 2047, 4095]
+        idx = [0, 1, B // 2 - 1, B - 1]
         for i in idx:
             eng.sample_begin(cond[i:i + 1], x_T[i:i + 1], inpaint=inpaint[i:i + 1], seed=3, sample_offset=i)
             eng.sample_run(0, N)
