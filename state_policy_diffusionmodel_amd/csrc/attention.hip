@@ -110,11 +110,8 @@ hipError_t launch_attention(const float* qkv, float* out, int B, int L, int C, i
 #define SPDM_ATT(DD)                                                                                          \
     {                                                                                                         \
         auto kern = attention_kernel<DD>;                                                                     \
-        if (lds > 64 * 1024) {                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); \
-            if (e != hipSuccess) return e;                                                                    \
-        }                                                                                                     \
+        if (lds > 64 * 1024)                                                                                  \
+            if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e; \
         hipLaunchKernelGGL(kern, grid, block, lds, s, qkv, out, L, C, heads, G, GS, npairs);                  \
     }
     switch (d) {
@@ -330,11 +327,8 @@ static hipError_t launch_attention_mfma(const float* qkv, float* out, int B, int
     const size_t lds = ((size_t)2 * Lp * (D + 8) + (size_t)2 * 32 * MO * (Lp + 4)) * sizeof(_Float16);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = attention_mfma_kernel<D>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(160 * 1024));
-        if (e != hipSuccess) return e;
-    }
+    if (lds > 64 * 1024)
+        if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int qblocks = (L + 127) / 128;
     const int waves = std::min(4, (L + 31) / 32);
     hipLaunchKernelGGL(kern, dim3(B * heads * qblocks), dim3(64 * waves), lds, s, qkv, out, L, C, heads, qblocks);

@@ -706,13 +706,7 @@ static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s
     lds = std::max(lds, (size_t)(M_T * WN * 2 + M_T * N_T) * sizeof(float));     // epilogue staging: srow + output tile
     if (lds > 160 * 1024 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI, W2>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     const int grid = n_mtiles * g.n_tiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, g.slots);

@@ -606,13 +606,7 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     lds = std::max(lds, (size_t)((M_T / 2) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     hipLaunchKernelGGL(kern, dim3(n_mtiles * g.n_tiles), dim3(NTHR), lds, s, a, g.slots, NS);
     return hipGetLastError();

@@ -9,9 +9,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 namespace spdm {
+
+// Kernels that declare more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, a PER-DEVICE
+// function attribute: set it once per (device, kernel) -- a process may hold handles on several GPUs.
+inline hipError_t allow_full_lds(const void* kern) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, kern})) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e == hipSuccess) done.insert({dev, kern});
+    return e;
+}
 
 // GroupNorm(1,C) statistics are produced by the kernel that writes a tensor, as
 // per-(sample, tile) partial sums in fp64:  stats[(b*slots + slot)*2 + {0,1}] =

@@ -417,16 +417,10 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     const bool wlds = (nwave >= 4) && getenv("SPDM_SA_NO_WLDS") == nullptr;      // long sequences: weights staged in LDS
     const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr = false;
-    if (!attr) {
-        const void* ks[4] = {reinterpret_cast<const void*>(sa_fused64_kernel<true, true>), reinterpret_cast<const void*>(sa_fused64_kernel<true, false>),
-                             reinterpret_cast<const void*>(sa_fused64_kernel<false, true>), reinterpret_cast<const void*>(sa_fused64_kernel<false, false>)};
-        for (const void* k : ks) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-            if (e != hipSuccess) return e;
-        }
-        attr = true;
-    }
+    const void* kern = (L % 32 == 0) ? (wlds ? reinterpret_cast<const void*>(sa_fused64_kernel<true, true>) : reinterpret_cast<const void*>(sa_fused64_kernel<true, false>))
+                                     : (wlds ? reinterpret_cast<const void*>(sa_fused64_kernel<false, true>) : reinterpret_cast<const void*>(sa_fused64_kernel<false, false>));
+    if (lds > 64 * 1024)
+        if (hipError_t e = allow_full_lds(kern); e != hipSuccess) return e;
     const bool full = (L % 32 == 0);
     if (full && wlds) hipLaunchKernelGGL((sa_fused64_kernel<true, true>), dim3(B), dim3(64 * nwave), lds, s, a);
     else if (full) hipLaunchKernelGGL((sa_fused64_kernel<true, false>), dim3(B), dim3(64 * nwave), lds, s, a);
