@@ -158,7 +158,7 @@ __device__ __forceinline__ float exp_neg(float x) {
     return __builtin_amdgcn_exp2f(t) * (1.0f + tl * 0.69314718f);
 }
 
-template <int D>
+template <int D, bool FULL>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              int L, int C, int heads, int qblocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     constexpr int MO = (D + 31) / 32;      // 32-row tiles of O^T
     constexpr int KROW = D + 8;            // halfs per K row
     const int Lp = (L + 31) & ~31;
-    const int VROW = Lp + 4;               // halfs per V^T row
+    const int VROW = Lp + 8;                 // halfs per V^T row: 16-byte aligned rows, 4-bank skew between rows
     _Float16* Khi = reinterpret_cast<_Float16*>(smraw);
     _Float16* Klo = Khi + (size_t)Lp * KROW;
     _Float16* Vhi = Klo + (size_t)Lp * KROW;
@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     constexpr int D4 = D / 4;
     for (int i = tid; i < Lp * D4; i += nthr) {
         const int j = i / D4, c = i - j * D4;
+        // position of key j in a V^T row: inside each group of 16 keys the order is [0-3, 8-11, 4-7, 12-15] (bits 2 and 3
+        // swapped), which makes the 8 keys a lane half feeds to one P.V MFMA contiguous (one ds_read_b128)
+        const int jp = (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1);
         f32x4a kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
         if (j < L) {
             kv = *reinterpret_cast<const f32x4a*>(base + j * ld + C + c * 4);
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             Khi[j * KROW + c * 4 + e] = h;
             Klo[j * KROW + c * 4 + e] = l2;
             split1(vv[e] * 16.0f, h, l2);
-            Vhi[(c * 4 + e) * VROW + j] = h;
-            Vlo[(c * 4 + e) * VROW + j] = l2;
+            Vhi[(c * 4 + e) * VROW + jp] = h;
+            Vlo[(c * 4 + e) * VROW + jp] = l2;
         }
     }
     if (D < 32 * MO) {      // zero the padding rows of V^T (d = 16: rows 16..31)
@@ -252,22 +255,29 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_h, ql[ks], acc_s, 0, 0, 0);
             acc_s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_l, qh[ks], acc_s, 0, 0, 0);
         }
-        // online softmax over the block's 32 keys of this lane's query
+        // online softmax over the block's 32 keys of this lane's query, through v_exp_f32 directly:
+        // p x 1024 = exp2(acc_s c + (10 - m)), c = log2(e) / 256 (undoes the 16 x 16 operand pre-scale), running max m
+        // in log2 units -- one max, one fma, one exp2 per score
+        constexpr float SC = 1.44269504088896340736f / 256.0f;
         float sc[16];
-        float mloc = -1e30f;
+        float mraw = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            sc[r] = (key < L) ? acc_s[r] * (1.0f / 256.0f) : -1e30f;
-            mloc = fmaxf(mloc, sc[r]);
+            sc[r] = acc_s[r];
+            if (!FULL) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (key >= L) sc[r] = -3.0e38f;
+            }
+            mraw = fmaxf(mraw, sc[r]);
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m, mloc);
-        const float alpha = exp_neg(m - m_new);
+        mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+        const float m_new = fmaxf(m, mraw * SC);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        const float off = 10.0f - m_new;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sc[r] = exp_neg(sc[r] - m_new);
+            sc[r] = __builtin_amdgcn_exp2f(__fmaf_rn(sc[r], SC, off));
             psum += sc[r];
         }
         lsum = lsum * alpha + psum;
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 _Float16 h, l2;
-                split1(sc[8 * s2 + j] * 1024.0f, h, l2);
+                split1(sc[8 * s2 + j], h, l2);
                 p_h[s2][j] = h;
                 p_l[s2][j] = l2;
             }
@@ -289,13 +299,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             for (int r = 0; r < 16; ++r) acc_o[mo][r] *= alpha;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                // V^T[row mo*32 + li][keys kb*32 + 16 s2 + 4 kh + {0..3}, + 8 + {0..3}]
-                const _Float16* vr_h = Vhi + (mo * 32 + li) * VROW + kb * 32 + 16 * s2 + 4 * kh;
-                const _Float16* vr_l = Vlo + (mo * 32 + li) * VROW + kb * 32 + 16 * s2 + 4 * kh;
-                const f16x4a vh0 = *reinterpret_cast<const f16x4a*>(vr_h), vh1 = *reinterpret_cast<const f16x4a*>(vr_h + 8);
-                const f16x4a vl0 = *reinterpret_cast<const f16x4a*>(vr_l), vl1 = *reinterpret_cast<const f16x4a*>(vr_l + 8);
-                const f16x8a v_h = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
-                const f16x8a v_l = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+                const f16x8a v_h = *reinterpret_cast<const f16x8a*>(Vhi + (mo * 32 + li) * VROW + kb * 32 + 16 * s2 + 8 * kh);
+                const f16x8a v_l = *reinterpret_cast<const f16x8a*>(Vlo + (mo * 32 + li) * VROW + kb * 32 + 16 * s2 + 8 * kh);
                 acc_o[mo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_h[s2], acc_o[mo], 0, 0, 0);
                 acc_o[mo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_l[s2], acc_o[mo], 0, 0, 0);
                 acc_o[mo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h[s2], acc_o[mo], 0, 0, 0);
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         }
     }
     lsum += __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / (lsum * 16384.0f);          // p scale 1024 x v scale 16
+    const float inv = 1.0f / (lsum * 16.0f);             // lsum carries the x1024 of p; v scale 16
     if (q < L) {
         float* orow = out + ((size_t)b * L + q) * C + hd * D;
 #pragma unroll
@@ -324,9 +329,9 @@ template <int D>
 static hipError_t launch_attention_mfma(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s) {
     const int Lp = (L + 31) & ~31;
     constexpr int MO = (D + 31) / 32;
-    const size_t lds = ((size_t)2 * Lp * (D + 8) + (size_t)2 * 32 * MO * (Lp + 4)) * sizeof(_Float16);
+    const size_t lds = ((size_t)2 * Lp * (D + 8) + (size_t)2 * 32 * MO * (Lp + 8)) * sizeof(_Float16);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = attention_mfma_kernel<D>;
+    auto kern = (L % 32 == 0) ? attention_mfma_kernel<D, true> : attention_mfma_kernel<D, false>;
     if (lds > 64 * 1024)
         if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int qblocks = (L + 127) / 128;

@@ -624,8 +624,7 @@ bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
                         a.epi == EPI_STATS && a.row_stats == nullptr && a.K % CK == 0 &&
                         (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && getenv("SPDM_NO_WIDE") == nullptr;
     if (!common) return false;
-    const int nsmax = (g.m_tile == 128) ? 64 : 32;
-    if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > nsmax) return false;
+    if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > 64) return false;        // 6-bit packed sample index per staging pass
     if (g.m_tile == 128)            // small tiles: the tap-pair loop only (128-wide, taps walked in pairs)
         return g.n_tile == 128 && (a.taps == 9 || (a.taps == 3 && a.W == 1)) && a.K % 64 == 0 && getenv("SPDM_NO_WIDE128") == nullptr;
     if (g.m_tile != 256) return false;
