@@ -1,5 +1,6 @@
 // sa_fused.hip -- the whole SelfAttention block (models/Unet_FiLmLayer.py:71-82) of one trajectory in
-// ONE kernel, for the C = 64 levels (sa5: L = H/2 * 4, sa6: L = H * 8 tokens; L <= 256):
+// ONE kernel, for the C = 64 levels (sa5: L = H/2 * 4, sa6: L = H * 8 tokens; L <= 512, two workgroups per trajectory
+// above 256):
 //
 //   ln  = LayerNorm(x)                     qkv = ln W_in^T + b_in
 //   o_h = softmax(q_h k_h^T / sqrt d) v_h  (4 heads, d = 16)
@@ -148,12 +149,15 @@ __device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&
 // WLDS: the workgroup stages the weight matrices in LDS once (256 + 128 rows, two phases) and every wave reads its A
 // fragments from there -- for the long-sequence block (8 waves per trajectory) this replaces 8 x 98 KB of per-wave
 // L2 reads, whose latency the 2 waves per SIMD could not hide (40 % of wave cycles parked), by one 98 KB copy.
-template <bool FULL, bool WLDS>
+// PAIR (256 < L <= 512, horizons up to 64): TWO workgroups per trajectory, each owning 256 query tokens.  A block needs
+// K and V of all tokens, so every wave also projects K and V of its 32 partner tokens (same lane, other half) -- 2 extra
+// 32-row tile products per head pair, no exchange between workgroups.
+template <bool FULL, bool WLDS, bool PAIR>
 __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
     const int L = a.L;
     const int nwave = blockDim.x >> 6;
-    const int Lp = nwave * 32;
+    const int Lp = PAIR ? 2 * nwave * 32 : nwave * 32;
     const int VROW = Lp + 8;                       // halfs per V^T row (16-byte aligned rows, 4-bank skew between rows)
     _Float16* Khi = reinterpret_cast<_Float16*>(sa_smem);
     _Float16* Klo = Khi + (size_t)Lp * SA_KROW;
@@ -164,8 +168,11 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.x;
-    const int t = wave * 32 + li;                  // this lane's token
+    const int b = PAIR ? blockIdx.x >> 1 : blockIdx.x;
+    const int hf = PAIR ? (blockIdx.x & 1) : 0;
+    const int t = hf * 256 + wave * 32 + li;       // this lane's token
+    const int t2 = (1 - hf) * 256 + wave * 32 + li;        // PAIR: the partner token whose K / V this lane also projects
+    const int tp2 = (t2 & ~12) | ((t2 & 4) << 1) | ((t2 & 8) >> 1);
     // position of token t in a V^T row: inside each group of 16 keys the order is [0-3, 8-11, 4-7, 12-15] (bits 2 and 3
     // swapped), which makes the 8 keys a lane half feeds to one P.V MFMA (4 kh + 0..3 and 8 + 4 kh + 0..3) contiguous
     const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
@@ -186,25 +193,18 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         __syncthreads();
     }
 
-    // ---- x^T tiles of this token: register r of tile T = feature 32 T + (r&3) + 8 (r>>2) + 4 kh ----
-    s_f32x16 xt[2];
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const s_f32x4 v = *reinterpret_cast<const s_f32x4*>(xrow + 32 * T + 8 * g + 4 * kh);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xt[T][4 * g + j] = v[j];
+    // x^T tiles of a token: register r of tile T = feature 32 T + (r&3) + 8 (r>>2) + 4 kh.  They are (re)loaded where they
+    // are used (twice for LayerNorm 1, once for the residual: L2 hits) instead of living in 32 registers throughout.
+#define SA_LOAD_X(dst_, row_)                                                                            \
+    _Pragma("unroll") for (int T_ = 0; T_ < 2; ++T_)                                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                              \
+            const s_f32x4 v_ = *reinterpret_cast<const s_f32x4*>((row_) + 32 * T_ + 8 * g_ + 4 * kh);    \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) dst_[T_][4 * g_ + j_] = v_[j_];           \
         }
 
-    // ---- LayerNorm 1 and its B fragments ----
+    // (LayerNorm 1 and its B fragments are re-made per head pair inside the loop: 32 registers that need not live
+    //  through the attention phase)
     s_f16x8 bh[4], bl[4];
-    {
-        s_f32x16 ln[2];
-        sa_layernorm(xt, ln, a.ln1_g, a.ln1_b, kh);
-        sa_make_frags(ln, bh, bl);
-    }
-
     s_f32x16 av[2];                                // out-proj accumulator (scaled by 2048 until the end)
 #pragma unroll
     for (int T = 0; T < 2; ++T)
@@ -216,6 +216,12 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         s_f32x16 qt, kt, vt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { qt[r] = 0.f; kt[r] = 0.f; vt[r] = 0.f; }
+        {
+            s_f32x16 x1[2], ln[2];
+            SA_LOAD_X(x1, xrow)
+            sa_layernorm(x1, ln, a.ln1_g, a.ln1_b, kh);
+            sa_make_frags(ln, bh, bl);
+        }
         if (WLDS) {
             qt = sa_gemm_tile_lds(Wsh, Wsl, 32 * p, li, kh, bh, bl, qt);
             kt = sa_gemm_tile_lds(Wsh, Wsl, 64 + 32 * p, li, kh, bh, bl, kt);
@@ -238,6 +244,30 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             }
         }
 
+        s_f32x16 kt2, vt2;
+        if constexpr (PAIR) {
+            {   // LayerNorm-1 fragments of the partner token (re-made per head pair, into the same registers)
+                const float* xrow2 = a.x + ((size_t)b * L + min(t2, L - 1)) * SA_C;
+                s_f32x16 x2[2], ln2[2];
+                SA_LOAD_X(x2, xrow2)
+                sa_layernorm(x2, ln2, a.ln1_g, a.ln1_b, kh);
+                sa_make_frags(ln2, bh, bl);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { kt2[r] = 0.f; vt2[r] = 0.f; }
+            kt2 = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 64 + 32 * p, li, kh, bh, bl, kt2);
+            vt2 = sa_gemm_tile(a.wqkv_h, a.wqkv_l, 128 + 32 * p, li, kh, bh, bl, vt2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const s_f32x4 bk = *reinterpret_cast<const s_f32x4*>(a.bqkv + 64 + 32 * p + 8 * g + 4 * kh);
+                const s_f32x4 bv = *reinterpret_cast<const s_f32x4*>(a.bqkv + 128 + 32 * p + 8 * g + 4 * kh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kt2[4 * g + j] = kt2[4 * g + j] * SA_DESCALE + bk[j];
+                    vt2[4 * g + j] = vt2[4 * g + j] * SA_DESCALE + bv[j];
+                }
+            }
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int head = 2 * p + sub;
@@ -262,6 +292,25 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 Vhi[dd * VROW + tp] = h;
                 Vlo[dd * VROW + tp] = l;
             }
+            if constexpr (PAIR) {
+                s_f16x8 k2_h, k2_l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 h, l;
+                    sa_split(kt2[8 * sub + j] * 16.0f, h, l);
+                    k2_h[j] = h; k2_l[j] = l;
+                }
+                *reinterpret_cast<s_f16x8*>(Khi + t2 * SA_KROW + 8 * kh) = k2_h;
+                *reinterpret_cast<s_f16x8*>(Klo + t2 * SA_KROW + 8 * kh) = k2_l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 h, l;
+                    sa_split(vt2[8 * sub + j] * 16.0f, h, l);
+                    const int dd = 8 * (j >> 2) + 4 * kh + (j & 3);
+                    Vhi[dd * VROW + tp2] = h;
+                    Vlo[dd * VROW + tp2] = l;
+                }
+            }
             __syncthreads();
 
             // ---- flash attention of this wave's 32 queries over all key blocks ----
@@ -269,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
             float m = -1e30f, lsum = 0.f;
-            for (int kb = 0; kb < nwave; ++kb) {
+            for (int kb = 0; kb < (L + 31) / 32; ++kb) {        // key blocks that hold at least one real token
                 s_f32x16 acc_s;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
@@ -351,7 +400,11 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     for (int T = 0; T < 2; ++T) {
         sa_bias(av[T], a.bo, T, kh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) av[T][r] += xt[T][r];
+        for (int g = 0; g < 4; ++g) {
+            const s_f32x4 v = *reinterpret_cast<const s_f32x4*>(xrow + 32 * T + 8 * g + 4 * kh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[T][4 * g + j] += v[j];
+        }
     }
     // ---- feed-forward: LN -> W1 -> GELU -> W2 -> + av ----
     if (WLDS) {                                     // phase B of the staged weights (every wave is past the out-proj reads)
@@ -398,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     }
 }
 
-bool sa_fused_supported(int L, int C) { return C == SA_C && L >= 1 && L <= 256; }
+bool sa_fused_supported(int L, int C) { return C == SA_C && L >= 1 && L <= 512; }
 
 hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
@@ -412,20 +465,20 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     a.w1_h = (const _Float16*)w_hl[4]; a.w1_l = (const _Float16*)w_hl[5];
     a.w2_h = (const _Float16*)w_hl[6]; a.w2_l = (const _Float16*)w_hl[7];
     a.bqkv = bqkv; a.bo = bo; a.b1 = b1; a.b2 = b2;
-    const int nwave = (L + 31) / 32;
-    const int Lp = nwave * 32;
-    const bool wlds = (nwave >= 4) && getenv("SPDM_SA_NO_WLDS") == nullptr;      // long sequences: weights staged in LDS
+    const bool pair = L > 256;                                                    // two workgroups per trajectory
+    const int nwave = pair ? 8 : (L + 31) / 32;
+    const int Lp = pair ? 512 : nwave * 32;
+    const bool wlds = !pair && (nwave >= 4) && getenv("SPDM_SA_NO_WLDS") == nullptr;      // long sequences: weights staged in LDS
     const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void* kern = (L % 32 == 0) ? (wlds ? reinterpret_cast<const void*>(sa_fused64_kernel<true, true>) : reinterpret_cast<const void*>(sa_fused64_kernel<true, false>))
-                                     : (wlds ? reinterpret_cast<const void*>(sa_fused64_kernel<false, true>) : reinterpret_cast<const void*>(sa_fused64_kernel<false, false>));
-    if (lds > 64 * 1024)
-        if (hipError_t e = allow_full_lds(kern); e != hipSuccess) return e;
     const bool full = (L % 32 == 0);
-    if (full && wlds) hipLaunchKernelGGL((sa_fused64_kernel<true, true>), dim3(B), dim3(64 * nwave), lds, s, a);
-    else if (full) hipLaunchKernelGGL((sa_fused64_kernel<true, false>), dim3(B), dim3(64 * nwave), lds, s, a);
-    else if (wlds) hipLaunchKernelGGL((sa_fused64_kernel<false, true>), dim3(B), dim3(64 * nwave), lds, s, a);
-    else hipLaunchKernelGGL((sa_fused64_kernel<false, false>), dim3(B), dim3(64 * nwave), lds, s, a);
+    void (*kern)(const SaFusedArgs) =
+        pair ? (full ? sa_fused64_kernel<true, false, true> : sa_fused64_kernel<false, false, true>)
+             : full ? (wlds ? sa_fused64_kernel<true, true, false> : sa_fused64_kernel<true, false, false>)
+                    : (wlds ? sa_fused64_kernel<false, true, false> : sa_fused64_kernel<false, false, false>);
+    if (lds > 64 * 1024)
+        if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(pair ? 2 * B : B), dim3(64 * nwave), lds, s, a);
     return hipGetLastError();
 }
 
