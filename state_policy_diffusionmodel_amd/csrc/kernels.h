@@ -158,4 +158,10 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
                              const float* bo, const float* b1, const float* b2, hipStream_t s);
 
+// ---- row-wise tail of a C = 128 SelfAttention block (sa_tail.hip): out_proj + x -> LayerNorm -> ff1 -> GELU -> ff2 + av ----
+bool sa_tail_supported(int C);
+hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
+                             const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
+                             const float* ln_b, hipStream_t s);
+
 }  // namespace spdm

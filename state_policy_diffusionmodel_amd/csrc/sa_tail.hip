@@ -1,0 +1,245 @@
+// sa_tail.hip -- the row-wise tail of a SelfAttention block with C = 128 channels (sa1, sa4) in ONE kernel:
+//
+//   av  = o W_o^T + b_o + x                       (out_proj + residual,        models/Unet_FiLmLayer.py:79-80)
+//   out = GELU(LayerNorm(av) W_1^T + b_1) W_2^T + b_2 + av      (ff_self + residual,               :63-68, :81)
+//
+// As three launches (conv_gemm_kernel<1 tap>) this chain moved 1.07 GB per step on sa1 -- every intermediate goes to
+// HBM and comes back -- for 77 GFLOP; here a workgroup owns 64 token rows end to end: it reads o and x, writes out
+// (0.4 GB), and the two intermediates live in LDS / registers.
+//
+//   * 4 waves, each a 32 x 64 accumulator tile (v_mfma_f32_16x16x32_f16, split-fp16 operands like every other
+//     contraction of the path: hi*hi + hi*lo + lo*hi into fp32);
+//   * the A operand of each product is a 64-row x 128-channel slab in LDS (conv_wide's row format: per 32-channel
+//     chunk [32 x fp16 hi | 32 x fp16 lo], rows padded to 144 bytes); weights come straight from global memory in
+//     fragment order (frag_order_weights, taps = 1), one 32-channel chunk ahead, also across the three products;
+//   * between products the accumulators go through LDS once (the dead slab's space) and are picked up ROW-WISE --
+//     thread (row 8 i + tid / 32, columns 4 (tid % 32) ..) for i = 0..7, the same assignment the loader uses -- so
+//     bias, residual, LayerNorm (two-pass over the 128 values of a row: a half-wave holds one row), GELU and the fp16
+//     split are register work, and av stays in 32 registers until the final residual.
+#include <algorithm>
+#include <cstdlib>
+
+#include "device_utils.h"
+
+namespace spdm {
+
+namespace {
+
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
+typedef float tf32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 tf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float T_ACT_SCALE = 16.0f;            // operand scales of the split scheme (activations 2^4, weights 2^7)
+constexpr float T_DESCALE = 1.0f / 2048.0f;
+constexpr int T_LDK = 36;                       // floats per LDS row of one 32-channel chunk (128 + 16 pad bytes)
+constexpr int T_C = 128, T_M = 64;           // 64 token rows per workgroup: 8 row pieces per thread (av + work set = 64 registers)
+
+struct SaTailArgs {
+    const float* o;        // [M][128] attention output (heads concatenated)
+    const float* x;        // [M][128] block input (residual of the out-projection)
+    float* out;            // [M][128]
+    int M;
+    const float *wf_o, *wf_1, *wf_2;            // fragment-order split weights (128 x 128 each)
+    const float *b_o, *b_1, *b_2, *ln_g, *ln_b;
+};
+
+__device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
+    const float xa = a * T_ACT_SCALE, xb = b * T_ACT_SCALE;
+    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
+    const tf16x2 h = {ha, hb};
+    const tf16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    return tf32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
+}
+// sum over the 32 lanes of a half-wave (xor offsets < 32 stay inside the half)
+__device__ __forceinline__ float thalf_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) {
+    constexpr int RT = 2, CT = 4;                       // per wave: 32 rows x 64 columns = 2 x 4 tiles of 16 x 16
+    constexpr int NP = T_M / 8;                         // row pieces per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, kg = lane >> 4;
+    const int M = a.M;
+    const int m0 = blockIdx.x * T_M;
+
+    float* Abuf = smem;                                 // [4 chunks][64 rows][T_LDK]  (36.9 KB)
+    float* otile = smem;                                // [64][128] fp32, aliases the slab between products
+
+    // row-wise piece i of this thread: row 8 i + srow0, columns 4 c16 .. 4 c16 + 3
+    const int c16 = tid & 31, srow0 = tid >> 5;
+    const int aoff0 = (wm * 32 + l16) * T_LDK + kg * 4;
+
+    // B operands of 32-channel chunk kc of a 128 x 128 weight: blocks (kc 8 + nb16) x {hi, lo} of 256 floats
+    const size_t wlane = ((size_t)(wn * CT) * 2) * 256 + lane * 4;
+    constexpr size_t WCHUNK = (size_t)8 * 2 * 256;
+    tf16x8 fb[2][CT][2], fa[2][2];
+#define TAIL_LOAD_B(slot_, w_, kc_)                                                                  \
+    {                                                                                                \
+        const float* p_ = (w_) + wlane + (size_t)(kc_) * WCHUNK;                                     \
+        _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_) {                                         \
+            fb[slot_][c_][0] = *reinterpret_cast<const tf16x8*>(p_ + c_ * 512);                      \
+            fb[slot_][c_][1] = *reinterpret_cast<const tf16x8*>(p_ + c_ * 512 + 256);                \
+        }                                                                                            \
+    }
+#define TAIL_LOAD_FA(slot_, kc_, rt_)                                                                \
+    {                                                                                                \
+        const float* p_ = Abuf + ((kc_) * T_M + (rt_) * 16) * T_LDK + aoff0;                         \
+        fa[slot_][0] = *reinterpret_cast<const tf16x8*>(p_);                                         \
+        fa[slot_][1] = *reinterpret_cast<const tf16x8*>(p_ + 16);                                    \
+    }
+    // slab <- the thread's 16 row pieces v_[i] (fp32), split to fp16 hi / lo
+#define TAIL_WRITE_SLAB(v_)                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                             \
+        const tf32x2 p0_ = tsplit2(v_[i_].x, v_[i_].y), p1_ = tsplit2(v_[i_].z, v_[i_].w);           \
+        float* rowp_ = Abuf + ((c16 >> 3) * T_M + 8 * i_ + srow0) * T_LDK;                           \
+        *reinterpret_cast<tf32x2*>(rowp_ + (c16 & 7) * 2) = tf32x2{p0_.x, p1_.x};                    \
+        *reinterpret_cast<tf32x2*>(rowp_ + 16 + (c16 & 7) * 2) = tf32x2{p0_.y, p1_.y};               \
+    }
+    // acc = slab . W^T over the four 32-channel chunks; the weights of `wnext_` chunk 0 are prefetched at the end
+#define TAIL_GEMM(w_, wnext_)                                                                        \
+    {                                                                                                \
+        _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_)                                        \
+            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) acc[rt_][ct_] = tf32x4{0.f, 0.f, 0.f, 0.f}; \
+        TAIL_LOAD_FA(0, 0, 0)                                                                        \
+        _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                          \
+            if (kc + 1 < 4) { TAIL_LOAD_B((kc + 1) & 1, w_, kc + 1) } else { TAIL_LOAD_B(0, wnext_, 0) } \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                     \
+                if (rt + 1 < RT) { TAIL_LOAD_FA((rt + 1) & 1, kc, rt + 1) }                          \
+                else if (kc + 1 < 4) { TAIL_LOAD_FA(0, kc + 1, 0) }                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                   \
+                _Pragma("unroll") for (int c = 0; c < CT; ++c)                                      \
+                    acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[rt & 1][0], fb[kc & 1][c][0], acc[rt][c], 0, 0, 0); \
+                _Pragma("unroll") for (int c = 0; c < CT; ++c)                                      \
+                    acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[rt & 1][0], fb[kc & 1][c][1], acc[rt][c], 0, 0, 0); \
+                _Pragma("unroll") for (int c = 0; c < CT; ++c)                                      \
+                    acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[rt & 1][1], fb[kc & 1][c][0], acc[rt][c], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                   \
+            }                                                                                        \
+        }                                                                                            \
+    }
+    // accumulators -> LDS tile (after every wave is done reading the slab), visible to all on return
+#define TAIL_ACC_TO_TILE()                                                                           \
+    {                                                                                                \
+        __syncthreads();                                                                             \
+        _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_)                                        \
+            _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) {                                  \
+                const int col_ = wn * 64 + ct_ * 16 + l16;                                           \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                    \
+                    otile[(wm * 32 + rt_ * 16 + 4 * kg + j_) * T_C + col_] = acc[rt_][ct_][j_] * T_DESCALE; \
+            }                                                                                        \
+        __syncthreads();                                                                             \
+    }
+
+    TAIL_LOAD_B(0, a.wf_o, 0)
+
+    // ---- slab <- o (attention output), raw ----
+    tf32x4 av[NP], v[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = min(m0 + 8 * i + srow0, M - 1);
+        v[i] = *reinterpret_cast<const tf32x4*>(a.o + (size_t)row * T_C + c16 * 4);
+        if (m0 + 8 * i + srow0 >= M) v[i] = tf32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    TAIL_WRITE_SLAB(v)
+    // the residual rows x are fetched now, into the registers that will hold av: in flight during the first product
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = min(m0 + 8 * i + srow0, M - 1);
+        av[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
+    }
+    __syncthreads();
+
+    tf32x4 acc[RT][CT];
+
+    // ---- av = o W_o^T + b_o + x ;  slab <- LayerNorm(av) ----
+    TAIL_GEMM(a.wf_o, a.wf_1)
+    TAIL_ACC_TO_TILE()
+    {
+        const tf32x4 bo = *reinterpret_cast<const tf32x4*>(a.b_o + c16 * 4);
+        const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
+        const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = 8 * i + srow0;
+            tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + r * T_C + c16 * 4);
+            t += bo;
+            t += av[i];
+            av[i] = t;
+            // LayerNorm over the row's 128 values (two-pass, like torch): the row sits on this half-wave
+            const float mean = thalf_sum((t.x + t.y) + (t.z + t.w)) * (1.0f / 128.0f);
+            const tf32x4 d = {t.x - mean, t.y - mean, t.z - mean, t.w - mean};
+            const float var = thalf_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);        // v_rsq_f32 (1 ulp)
+            v[i] = tf32x4{d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w};
+            __builtin_amdgcn_sched_barrier(0);          // one row piece at a time: register pressure
+        }
+    }
+    __syncthreads();                                    // every thread has read its pieces of the tile
+    TAIL_WRITE_SLAB(v)
+    __syncthreads();
+
+    // ---- f1 = GELU(ln W_1^T + b_1) ;  slab <- f1 ----
+    TAIL_GEMM(a.wf_1, a.wf_2)
+    TAIL_ACC_TO_TILE()
+    {
+        const tf32x4 b1 = *reinterpret_cast<const tf32x4*>(a.b_1 + c16 * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + (8 * i + srow0) * T_C + c16 * 4);
+            t += b1;
+            v[i] = tf32x4{gelu_erf(t.x), gelu_erf(t.y), gelu_erf(t.z), gelu_erf(t.w)};
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    TAIL_WRITE_SLAB(v)
+    __syncthreads();
+
+    // ---- out = f1 W_2^T + b_2 + av ----
+    TAIL_GEMM(a.wf_2, a.wf_2)                           // (the trailing prefetch re-reads a valid block; unused)
+    TAIL_ACC_TO_TILE()
+    {
+        const tf32x4 b2 = *reinterpret_cast<const tf32x4*>(a.b_2 + c16 * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = 8 * i + srow0;
+            if (m0 + r < M) {
+                tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + r * T_C + c16 * 4);
+                t += b2;
+                t += av[i];
+                *reinterpret_cast<tf32x4*>(a.out + (size_t)(m0 + r) * T_C + c16 * 4) = t;
+            }
+        }
+    }
+#undef TAIL_LOAD_B
+#undef TAIL_LOAD_FA
+#undef TAIL_WRITE_SLAB
+#undef TAIL_GEMM
+#undef TAIL_ACC_TO_TILE
+}
+
+}  // namespace
+
+bool sa_tail_supported(int C) { return C == T_C && getenv("SPDM_NO_SA_TAIL") == nullptr; }
+
+hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
+                             const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
+                             const float* ln_b, hipStream_t s) {
+    if (rows <= 0 || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
+        return hipErrorInvalidValue;
+    SaTailArgs a{};
+    a.o = o; a.x = x; a.out = out; a.M = rows;
+    a.wf_o = wf_o; a.wf_1 = wf_1; a.wf_2 = wf_2;
+    a.b_o = b_o; a.b_1 = b_1; a.b_2 = b_2; a.ln_g = ln_g; a.ln_b = ln_b;
+    const size_t lds = (size_t)4 * T_M * T_LDK * sizeof(float);          // 36.9 KB
+    hipLaunchKernelGGL(sa_tail128_kernel, dim3((rows + T_M - 1) / T_M), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace spdm

@@ -119,6 +119,7 @@ struct AttnW {
     float* ln_g = nullptr; float* ln_b = nullptr; float* ff_ln_g = nullptr; float* ff_ln_b = nullptr;
     int C = 0;
     void* fw[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fused-kernel weights (C == 64)
+    float* tail_wf[3] = {nullptr, nullptr, nullptr};   // fragment-order split copies of out_proj / ff1 / ff2 (C == 128: sa_tail.hip)
 };
 
 struct ProfEvt { hipEvent_t a, b; double flops; };
@@ -490,9 +491,20 @@ struct Loader {
             *(which ? lo_dev : hi_dev) = d;
         }
     }
+    // fragment-order split copy of a (out, in) Linear weight (sa_tail.hip reads its B operands straight from it)
+    float* linear_frag(const std::string& wname, int out, int in) {
+        const float* w = find(wname, {out, in});
+        if (!w) return nullptr;
+        return upload(frag_order_weights(split_format(std::vector<float>(w, w + (size_t)out * in)), 1, out, in));
+    }
     AttnW attn(const std::string& p, int C) {
         AttnW a;
         a.C = C;
+        if (C == 128) {
+            a.tail_wf[0] = linear_frag(p + ".attention.out_proj.weight", C, C);
+            a.tail_wf[1] = linear_frag(p + ".ff_self.1.weight", C, C);
+            a.tail_wf[2] = linear_frag(p + ".ff_self.3.weight", C, C);
+        }
         if (C == 64) {
             perm_split(p + ".attention.in_proj_weight", 192, &a.fw[0], &a.fw[1]);
             perm_split(p + ".attention.out_proj.weight", 64, &a.fw[2], &a.fw[3]);
@@ -772,6 +784,16 @@ struct Ctx {
         Tensor att = ralloc(rows, C);
         if (!err && !dry) check(launch_attention_auto(qkv.p, att.p, B, L, C, 4, s), "attention core");
         free(qkv);
+        if (h->split && sa_tail_supported(C) && (dry || w.tail_wf[0])) {
+            // out_proj + residual + LayerNorm + ff_self + residual in one kernel (sa_tail.hip)
+            Tensor out = talloc(C, level);
+            if (!err && !dry)
+                check(launch_sa_tail128(att.p, x.p, out.p, rows, w.tail_wf[0], w.tail_wf[1], w.tail_wf[2], w.out_proj.b, w.ff1.b,
+                                        w.ff2.b, w.ff_ln_g, w.ff_ln_b, s), "attention tail");
+            free(att);
+            free(x);
+            return out;
+        }
         Tensor av = talloc(C, level);
         const int nt_av = gemm_geometry(rows, C, 1, 1, (h->split && C % 32 == 0) ? 1 : 0).n_tiles;   // n-tiles of the out_proj GEMM
         StatsBuf avs = row_stats_alloc(rows, C, nt_av);
