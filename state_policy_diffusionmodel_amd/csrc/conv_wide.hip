@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     constexpr int FAR = W2 ? 4 : 3;                     // A-fragment ring (row tiles)
     constexpr int FBR = (NT == 2) ? 2 : 3;              // B-fragment ring (phases)
     constexpr int PH = 3 * NT;                          // phases per kernel row (generic layout)
-    constexpr int BB = (APASS <= 10) ? 6 : 5;           // bits per staging pass of the packed sample index
+    constexpr int BB = (APASS <= 9) ? 7 : (APASS <= 10) ? 6 : 5;   // bits per staging pass of the packed sample index
     static_assert(APASS * BB <= 64, "sample-index packing");
     static_assert(!W2 || NT == 2, "the width-2 variant exists for 128-wide tiles");
     static_assert(RT == 8 || (RT == 4 && NT == 2 && !W2), "64-row waves only in the tap-pair loop");
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = (4 / WN) * RT * 16, N_T = WN * 32 * NT, NTHR = 256;
-    constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 10) ? 64 : 32;
+    constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 9) ? 128 : (APASS <= 10) ? 64 : 32;
     const int halo = a.W + 1;
     const int QA = M_T + 2 * halo;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
@@ -624,11 +624,12 @@ bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
                         a.epi == EPI_STATS && a.row_stats == nullptr && a.K % CK == 0 &&
                         (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && getenv("SPDM_NO_WIDE") == nullptr;
     if (!common) return false;
-    if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > 64) return false;        // 6-bit packed sample index per staging pass
+    if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > 128) return false;       // 7-bit packed sample index per staging pass
     if (g.m_tile == 128)            // small tiles: the tap-pair loop only (128-wide, taps walked in pairs)
         return g.n_tile == 128 && (a.taps == 9 || (a.taps == 3 && a.W == 1)) && a.K % 64 == 0 && getenv("SPDM_NO_WIDE128") == nullptr;
     if (g.m_tile != 256) return false;
-    if (a.taps == 3) return a.W == 1 && g.n_tile == 128 && a.K % 64 == 0;
+    if (a.taps == 3) return false;       // 256-row tiles of the W == 1 level (one workgroup per CU at most): conv_gemm's 8-wave
+                                         // configuration measured faster (92 vs 139 us on 512 -> 512 at B = 4096)
     if (a.taps != 9 || !(g.n_tile == 128 || g.n_tile == 64)) return false;
     // width-2 maps: only with the zero-tap skipping variant (otherwise conv_gemm.hip's W2 configuration does less work)
     if (wide_w2(a)) return g.n_tile == 128 && (a.HW & 7) == 0;
