@@ -666,6 +666,9 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
     const int nt_pref = nt128 ? nt128 : N / 64;
     bool big = split && taps != 1 && M >= 256;
     if (big && (long long)((M + 255) / 256) * nt_pref < 192) big = false;
+    // 3-tap convs (W == 1 level): 128-row tiles (conv_wide's 4 x (64 x 64) variant, two workgroups per CU) until the
+    // 256-row tiling would give every CU two workgroups
+    if (big && taps == 3 && HW % 4 == 0 && (long long)((M + 255) / 256) * nt_pref < 512 && getenv("SPDM_T3_BIG") == nullptr) big = false;
     g.m_tile = big ? 256 : 128;
     g.n_tile = nt128 ? 128 : 64;
     if (!big && nt128 && (long long)((M + 127) / 128) * nt128 < 192) g.n_tile = 64;
