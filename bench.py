@@ -156,7 +156,7 @@ def main():
 
     eng.sample_begin(cond, x_T, noise=None, inpaint=inpaint, seed=7, sample_offset=rank * B)
     eng.sample_run(0, W)                                   # untimed warm-up steps
-    eng.profile(True)                                      # HIP events around every conv3x3 launch
+    eng.profile(True)                                      # HIP events around every run of consecutive conv3x3 launches
     barrier()
     t0 = time.perf_counter()
     eng.sample_run(W, W + K)                               # EXACTLY K denoise steps

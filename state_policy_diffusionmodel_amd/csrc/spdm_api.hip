@@ -122,7 +122,7 @@ struct AttnW {
     float* tail_wf[3] = {nullptr, nullptr, nullptr};   // fragment-order split copies of out_proj / ff1 / ff2 (C == 128: sa_tail.hip)
 };
 
-struct ProfEvt { hipEvent_t a, b; double flops; };
+struct ProfEvt { hipEvent_t a, b; double flops; int launches; };
 
 struct spdm_handle {
     spdm_config cfg{};
@@ -182,6 +182,7 @@ struct spdm_handle {
     // profiling of the dominant kernel class
     bool prof = false;
     std::vector<ProfEvt> prof_evts;
+    int prof_open = -1;                   // index of the event pair that brackets the current run of consecutive conv launches
     long long prof_launches = 0;
     double prof_ms = 0.0, prof_flops = 0.0;
 };
@@ -712,19 +713,33 @@ struct Ctx {
         if (in.pending_gn()) { a.pro_stats = in.st.ref; a.pro_gamma = in.gamma; a.pro_beta = in.beta; }
         a.epi = EPI_STATS; a.epi_stats = out.st.p;
         if (in.t.C != w.cin) { if (!err) err = fail(SPDM_ERR_INVALID, "plan: conv input has %d channels, weight expects %d", in.t.C, w.cin); return out; }
-        ProfEvt* pe = nullptr;
-        if (h->prof) {
-            ProfEvt e{};
-            if (hipEventCreate(&e.a) == hipSuccess && hipEventCreate(&e.b) == hipSuccess) {
-                e.flops = gemm_flops(a);
-                h->prof_evts.push_back(e);
-                pe = &h->prof_evts.back();
-                (void)hipEventRecord(pe->a, s);
-            }
+        // Profiling (spdm_profile_*): HIP events on the launch stream.  Runs of CONSECUTIVE conv launches (the two
+        // DoubleConvolutions of a block: nothing else is launched in between) share one event pair -- every event
+        // record is a queue barrier that costs the neighbouring kernels their overlap (62 records per step were
+        // worth 0.25 ms), and the class average only needs total time / launches.
+        const bool solo = h->prof && h->prof_open < 0;
+        if (solo) prof_begin();
+        if (h->prof && h->prof_open >= 0) {
+            h->prof_evts[h->prof_open].flops += gemm_flops(a);
+            h->prof_evts[h->prof_open].launches += 1;
         }
         check(launch_gemm(a, s), "conv3x3 implicit GEMM");
-        if (pe) (void)hipEventRecord(pe->b, s);
+        if (solo) prof_end();
         return out;
+    }
+    void prof_begin() {
+        if (!h->prof || h->prof_open >= 0 || dry || err) return;
+        ProfEvt e{};
+        if (hipEventCreate(&e.a) == hipSuccess && hipEventCreate(&e.b) == hipSuccess) {
+            h->prof_evts.push_back(e);
+            h->prof_open = (int)h->prof_evts.size() - 1;
+            (void)hipEventRecord(e.a, s);
+        }
+    }
+    void prof_end() {
+        if (h->prof_open < 0) return;
+        (void)hipEventRecord(h->prof_evts[h->prof_open].b, s);
+        h->prof_open = -1;
     }
     // DoubleConvolution.forward, models/Unet_FiLmLayer.py:108-115.  Consumes `in`.
     Value double_conv(Value& in, const DoubleConvW& w, int level, bool keep_in = false) {
@@ -855,8 +870,10 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         if (!c.err && !c.dry)
             c.check(launch_pool(c.asrc(cur), p.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "maxpool");
         // `cur` stays alive: it is a skip connection
+        c.prof_begin();
         Value a = c.double_conv(p, h->down[i].dc1, lout);
         Value b2 = c.double_conv(a, h->down[i].dc2, lout);
+        c.prof_end();
         StatsBuf ys;
         Tensor y = c.film_tail(b2, h->down[i], i, lout, use_cond,
                                (h->cfg.attention && !c.sa_fused(h->sa[i], lout)) ? &ys : nullptr);
@@ -869,9 +886,11 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         if (i < 2) skips[i + 1] = nv;
     }
     // ---- bottleneck (:297-299) ----
+    c.prof_begin();
     Value b1 = c.double_conv(cur, h->bot[0], 3);
     Value b2 = c.double_conv(b1, h->bot[1], 3);
     Value x5 = c.double_conv(b2, h->bot[2], 3);         // pending GN
+    c.prof_end();
     if (h->arena.keep) {
         Tensor m = c.talloc(256, 3);
         if (!c.dry && !c.err) c.check(launch_gn_apply(c.asrc(x5), m.p, B, c.HWl(3), c.s), "gn_apply");
@@ -890,8 +909,10 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
             c.check(launch_upcat(c.asrc(cur), c.asrc(skip), cat.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "upsample+concat");
         c.free(cur);
         c.free(skip);
+        c.prof_begin();
         Value a = c.double_conv(cat, h->up[i].dc1, lout);
         Value b3 = c.double_conv(a, h->up[i].dc2, lout);
+        c.prof_end();
         StatsBuf ys;
         Tensor y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond,
                                (h->cfg.attention && !c.sa_fused(h->sa[3 + i], lout)) ? &ys : nullptr);
@@ -1156,6 +1177,7 @@ extern "C" int spdm_profile_enable(spdm_handle* h, int32_t on) {
     h->prof = on != 0;
     for (auto& e : h->prof_evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->prof_evts.clear();
+    h->prof_open = -1;
     h->prof_launches = 0; h->prof_ms = 0.0; h->prof_flops = 0.0;
     return SPDM_OK;
 }
@@ -1167,7 +1189,7 @@ extern "C" int spdm_profile_read(spdm_handle* h, int64_t* launches, double* tota
     for (auto& e : h->prof_evts) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            h->prof_ms += ms; h->prof_flops += e.flops; h->prof_launches += 1;
+            h->prof_ms += ms; h->prof_flops += e.flops; h->prof_launches += e.launches;
         }
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
