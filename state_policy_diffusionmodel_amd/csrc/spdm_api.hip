@@ -170,8 +170,9 @@ struct spdm_handle {
         int B = 0, inp_h = 0, per_sample = 0, have_film = 0, sched_kind = 0, n_steps = 0;
         const void *inpaint = nullptr, *noise = nullptr, *history = nullptr;
         unsigned long long seed = 0, offset = 0;
+        unsigned env = 0;                 // which kernel-selection switches (SPDM_NO_WIDE, ...) were set when the step was captured
         bool operator==(const StepGraphKey& o) const {
-            return B == o.B && inp_h == o.inp_h && per_sample == o.per_sample && have_film == o.have_film &&
+            return env == o.env && B == o.B && inp_h == o.inp_h && per_sample == o.per_sample && have_film == o.have_film &&
                    sched_kind == o.sched_kind && n_steps == o.n_steps && inpaint == o.inpaint && noise == o.noise &&
                    history == o.history && seed == o.seed && offset == o.offset;
         }
@@ -1113,6 +1114,13 @@ extern "C" int spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_
         key.B = h->sB; key.inp_h = h->s_inp_h; key.per_sample = h->s_inp_per_sample; key.have_film = h->have_film ? 1 : 0;
         key.sched_kind = h->sched_kind; key.n_steps = h->n_steps; key.inpaint = h->s_inpaint; key.noise = h->s_noise;
         key.history = h->s_history; key.seed = h->s_seed; key.offset = h->s_offset;
+        {   // the captured launches depend on the kernel-selection switches too (tests flip them inside one process)
+            static const char* const sw[] = {"SPDM_ATTN_VALU", "SPDM_NO_SA_FUSED", "SPDM_NO_SA_TAIL", "SPDM_NO_T512", "SPDM_NO_W2",
+                                             "SPDM_NO_WIDE", "SPDM_NO_WIDE128", "SPDM_SA_NO_WLDS", "SPDM_T3_BIG", "SPDM_T512",
+                                             "SPDM_WIDE_N64_2X2"};
+            for (unsigned k = 0; k < sizeof(sw) / sizeof(sw[0]); ++k)
+                if (getenv(sw[k]) != nullptr) key.env |= 1u << k;
+        }
         if (!(h->step_exec && key == h->graph_key)) {
             if (build_step_graph(h, s)) h->graph_key = key;
             else use_graph = false;
