@@ -163,5 +163,8 @@ bool sa_tail_supported(int C);
 hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                              const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
                              const float* ln_b, hipStream_t s);
+// qkv = LayerNorm(x) W_in^T + b_in of the same blocks (LayerNorm from the row itself)
+hipError_t launch_sa_qkv128(const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
+                            const float* ln_b, hipStream_t s);
 
 }  // namespace spdm

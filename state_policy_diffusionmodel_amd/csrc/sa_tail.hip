@@ -217,6 +217,92 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
             }
         }
     }
+}
+
+// ---- the head of the same blocks:  qkv = LayerNorm(x) W_in^T + b_in   (self.ln -> mha in_proj, :76-79) -----------
+// Same workgroup shape and machinery (the macros above): 64 token rows, LayerNorm computed from the row itself (two
+// passes over its 128 values in a half-wave -- no statistics from the producer needed), ONE normalised slab feeding
+// three 128-column products (q, k, v), each stored straight from its row-wise pick-up.  As conv_gemm_kernel<1 tap>
+// this GEMM re-read the input once per 128-column tile and took its LayerNorm statistics from HBM.
+struct SaQkvArgs {
+    const float* x; float* qkv; int M;          // [M][128] -> [M][384]
+    const float* wf;                            // fragment-order split in_proj weight (384 x 128)
+    const float *b_in, *ln_g, *ln_b;
+};
+
+__global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
+    constexpr int RT = 2, CT = 4;
+    constexpr int NP = T_M / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, kg = lane >> 4;
+    const int M = a.M;
+    const int m0 = blockIdx.x * T_M;
+    float* Abuf = smem;
+    float* otile = smem;
+    const int c16 = tid & 31, srow0 = tid >> 5;
+    const int aoff0 = (wm * 32 + l16) * T_LDK + kg * 4;
+    // in_proj is 384 x 128: product g (q, k, v) uses rows 128 g .. -> 16-column blocks 8 g ..; chunk stride = 24 blocks
+    const size_t wlane = ((size_t)(wn * CT) * 2) * 256 + lane * 4;
+    constexpr size_t WCHUNK = (size_t)24 * 2 * 256;
+    constexpr size_t WPROD = (size_t)8 * 2 * 256;
+    tf16x8 fb[2][CT][2], fa[2][2];
+    tf32x4 acc[RT][CT], v[NP];
+
+    TAIL_LOAD_B(0, a.wf, 0)
+    {
+        const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
+        const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = min(m0 + 8 * i + srow0, M - 1);
+            v[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const tf32x4 t = v[i];
+            const float mean = thalf_sum((t.x + t.y) + (t.z + t.w)) * (1.0f / 128.0f);
+            const tf32x4 d = {t.x - mean, t.y - mean, t.z - mean, t.w - mean};
+            const float var = thalf_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+            v[i] = tf32x4{d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w};
+        }
+    }
+    TAIL_WRITE_SLAB(v)
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float* wg = a.wf + (size_t)g * WPROD;
+        const float* wnext = a.wf + (size_t)(g < 2 ? g + 1 : g) * WPROD;       // the last trailing prefetch re-reads a valid block
+        TAIL_GEMM(wg, wnext)
+        // accumulators -> LDS: the slab must survive for the next product, so the tile goes BEHIND it
+        {
+            float* ot = smem + 4 * T_M * T_LDK;
+            if (g > 0) __syncthreads();                 // every thread has picked up the previous product's rows
+#pragma unroll
+            for (int rt_ = 0; rt_ < RT; ++rt_)
+#pragma unroll
+                for (int ct_ = 0; ct_ < CT; ++ct_) {
+                    const int col_ = wn * 64 + ct_ * 16 + l16;
+#pragma unroll
+                    for (int j_ = 0; j_ < 4; ++j_)
+                        ot[(wm * 32 + rt_ * 16 + 4 * kg + j_) * T_C + col_] = acc[rt_][ct_][j_] * T_DESCALE;
+                }
+            __syncthreads();
+            const tf32x4 bi = *reinterpret_cast<const tf32x4*>(a.b_in + g * T_C + c16 * 4);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int r = 8 * i + srow0;
+                if (m0 + r < M) {
+                    tf32x4 t = *reinterpret_cast<const tf32x4*>(ot + r * T_C + c16 * 4);
+                    t += bi;
+                    *reinterpret_cast<tf32x4*>(a.qkv + (size_t)(m0 + r) * (3 * T_C) + g * T_C + c16 * 4) = t;
+                }
+            }
+        }
+    }
+    (void)otile;
 #undef TAIL_LOAD_B
 #undef TAIL_LOAD_FA
 #undef TAIL_WRITE_SLAB
@@ -239,6 +325,17 @@ hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int row
     a.b_o = b_o; a.b_1 = b_1; a.b_2 = b_2; a.ln_g = ln_g; a.ln_b = ln_b;
     const size_t lds = (size_t)4 * T_M * T_LDK * sizeof(float);          // 36.9 KB
     hipLaunchKernelGGL(sa_tail128_kernel, dim3((rows + T_M - 1) / T_M), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sa_qkv128(const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
+                            const float* ln_b, hipStream_t s) {
+    if (rows <= 0 || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
+    SaQkvArgs a{};
+    a.x = x; a.qkv = qkv; a.M = rows; a.wf = wf_in; a.b_in = b_in; a.ln_g = ln_g; a.ln_b = ln_b;
+    const size_t lds = (size_t)(4 * T_M * T_LDK + T_M * T_C) * sizeof(float);     // slab 36.9 KB + output tile 32 KB
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(sa_qkv128_kernel)); e != hipSuccess) return e;
+    hipLaunchKernelGGL(sa_qkv128_kernel, dim3((rows + T_M - 1) / T_M), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -120,6 +120,7 @@ struct AttnW {
     int C = 0;
     void* fw[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fused-kernel weights (C == 64)
     float* tail_wf[3] = {nullptr, nullptr, nullptr};   // fragment-order split copies of out_proj / ff1 / ff2 (C == 128: sa_tail.hip)
+    float* qkv_wf = nullptr;                           // ... and of in_proj
 };
 
 struct ProfEvt { hipEvent_t a, b; double flops; int launches; };
@@ -506,6 +507,7 @@ struct Loader {
             a.tail_wf[0] = linear_frag(p + ".attention.out_proj.weight", C, C);
             a.tail_wf[1] = linear_frag(p + ".ff_self.1.weight", C, C);
             a.tail_wf[2] = linear_frag(p + ".ff_self.3.weight", C, C);
+            a.qkv_wf = linear_frag(p + ".attention.in_proj_weight", 3 * C, C);
         }
         if (C == 64) {
             perm_split(p + ".attention.in_proj_weight", 192, &a.fw[0], &a.fw[1]);
@@ -795,7 +797,12 @@ struct Ctx {
             return out;
         }
         Tensor qkv = ralloc(rows, 3 * C);
-        linear(x.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr, &xs, w.ln_g, w.ln_b);
+        if (h->split && sa_tail_supported(C) && (dry || w.qkv_wf)) {     // LayerNorm + in_proj in one 64-row kernel (sa_tail.hip)
+            if (!err && !dry)
+                check(launch_sa_qkv128(x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, s), "attention in_proj");
+        } else {
+            linear(x.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr, &xs, w.ln_g, w.ln_b);
+        }
         free(xs);
         Tensor att = ralloc(rows, C);
         if (!err && !dry) check(launch_attention_auto(qkv.p, att.p, B, L, C, 4, s), "attention core");
