@@ -166,7 +166,19 @@ __global__ __launch_bounds__(256) void upcat_kernel(const AffineSrc up, const Af
     block_sample_stats(up, b, sm_u, mu_u, rs_u);
     block_sample_stats(skip, b, sm_s, mu_s, rs_s);
     const int Cu = up.C, Cs = skip.C, C = Cu + Cs, C4 = C >> 2;
-    const int c4 = tid % C4, rl = tid / C4, rpp = 256 / C4;
+    // thread -> (row, 4-channel group).  When both halves are equally wide (every level of this U-Net) the first 128
+    // threads take the upsampled channels and the last 128 the skip channels, so that a wave runs ONE of the two
+    // paths (4 gathered loads + blend, or 1 load) instead of both with half its lanes masked.
+    int c4, rl;
+    const int rpp = 256 / C4;
+    if (Cu == Cs && C4 <= 128) {
+        const int h4 = C4 >> 1, part = tid >> 7, t2 = tid & 127;
+        c4 = part * h4 + t2 % h4;
+        rl = t2 / h4;
+    } else {
+        c4 = tid % C4;
+        rl = tid / C4;
+    }
     const int Ho = 2 * Hin, Wo = 2 * Win, HWo = Ho * Wo;
     const bool is_up = (c4 * 4 < Cu);
     const int cl = is_up ? c4 * 4 : c4 * 4 - Cu;
