@@ -3,6 +3,8 @@
 // LayerNorm, Mish/SiLU, and the fused "1x1 out conv + unpad + DDPM/DDIM update + inpaint" step
 // kernel.  All of them are HBM-bound: channels-last rows, float4 (16 B) per lane, every wave
 // instruction touches whole 128-byte lines.
+#include <algorithm>
+
 #include "device_utils.h"
 
 namespace spdm {
@@ -269,6 +271,35 @@ __global__ __launch_bounds__(256) void film_apply_kernel(const AffineSrc src, co
             }
         }
     }
+}
+
+// The same tail as a per-(sample, channel) affine  y = A x + B  for consumers that apply it while LOADING the raw conv
+// output (sa_fused64_kernel, sa_qkv128_kernel, sa_tail128_kernel) instead of reading a materialised y:
+//   A = scale * rstd * gamma,   B = scale * (beta - mean * rstd * gamma + emb_t) + bias;   ab[b] = [A (C) | B (C)]
+__global__ __launch_bounds__(256) void film_coef_kernel(const AffineSrc src, const float* __restrict__ temb,
+                                                        const int* __restrict__ t_dev, int t_count,
+                                                        const float* __restrict__ film, float* __restrict__ ab) {
+    __shared__ float sm[2];
+    const int b = blockIdx.x;
+    float mean, rstd;
+    block_sample_stats(src, b, sm, mean, rstd);
+    const int C = src.C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sc = 1.f, be = 0.f;
+        if (src.st.p != nullptr) { sc = rstd * src.gamma[c]; be = src.beta[c] - mean * sc; }
+        if (temb != nullptr) be += temb[(size_t)t_dev[t_count == 1 ? 0 : b] * C + c];
+        float fs = 1.f, fb = 0.f;
+        if (film != nullptr) { fs = film[(size_t)b * 2 * C + c]; fb = film[(size_t)b * 2 * C + C + c]; }
+        ab[(size_t)b * 2 * C + c] = fs * sc;
+        ab[(size_t)b * 2 * C + C + c] = fs * be + fb;
+    }
+}
+hipError_t launch_film_coef(const AffineSrc& src, const float* temb_table, const int* t_dev, int t_count, const float* film,
+                            float* ab, int B, hipStream_t s) {
+    if (B <= 0 || src.C <= 0 || ab == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(film_coef_kernel, dim3(B), dim3(std::min(256, ((src.C + 63) / 64) * 64)), 0, s, src, temb_table, t_dev,
+                       t_count, film, ab);
+    return hipGetLastError();
 }
 
 hipError_t launch_film_apply(const AffineSrc& src, const float* temb_table, const int* t_dev, int t_count,

@@ -119,6 +119,9 @@ hipError_t launch_upcat(const AffineSrc& up, const AffineSrc& skip, float* dst, 
 hipError_t launch_film_apply(const AffineSrc& src, const float* temb_table /*[T][C]*/, const int* t_dev,
                              int t_count, const float* film /*[B][2C] or null*/, float* dst, double* row_stats,
                              int B, int HW, hipStream_t s);
+// the same tail as per-(sample, channel) coefficients ab[b] = [A (C) | B (C)], y = A x + B, for consumers that apply it on load
+hipError_t launch_film_coef(const AffineSrc& src, const float* temb_table, const int* t_dev, int t_count, const float* film,
+                            float* ab, int B, hipStream_t s);
 // plain GN apply (materialise): y = GN(x)
 hipError_t launch_gn_apply(const AffineSrc& src, float* dst, int B, int HW, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int C,
@@ -154,17 +157,18 @@ hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int
 bool sa_fused_supported(int L, int C);
 // w_hl: {Wqkv hi, lo, Wo hi, lo, W1 hi, lo, W2 hi, lo} as fp16 [rows][64], input axis permuted by perm16 inside
 // each group of 16, pre-scaled by 128 (spdm_api.hip: Loader::perm_split)
+// ab (optional): the block input is ab-affine of x per sample (film_coef_kernel), applied on load
 hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
-                             const float* bo, const float* b1, const float* b2, hipStream_t s);
+                             const float* bo, const float* b1, const float* b2, const float* ab, hipStream_t s);
 
 // ---- row-wise tail of a C = 128 SelfAttention block (sa_tail.hip): out_proj + x -> LayerNorm -> ff1 -> GELU -> ff2 + av ----
 bool sa_tail_supported(int C);
 hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                              const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
-                             const float* ln_b, hipStream_t s);
+                             const float* ln_b, const float* ab, int L, hipStream_t s);
 // qkv = LayerNorm(x) W_in^T + b_in of the same blocks (LayerNorm from the row itself)
 hipError_t launch_sa_qkv128(const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
-                            const float* ln_b, hipStream_t s);
+                            const float* ln_b, const float* ab, int L, hipStream_t s);
 
 }  // namespace spdm

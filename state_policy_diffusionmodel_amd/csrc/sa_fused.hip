@@ -43,6 +43,7 @@ struct SaFusedArgs {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     const _Float16 *wqkv_h, *wqkv_l, *wo_h, *wo_l, *w1_h, *w1_l, *w2_h, *w2_l;   // [rows][64], permuted, x128
     const float *bqkv, *bo, *b1, *b2;
+    const float* ab;       // optional [B][2][64]: the block input is y = A x + B per sample (FiLM tail folded into the load)
 };
 
 __device__ __forceinline__ void sa_split(float x, _Float16& hi, _Float16& lo) {
@@ -198,9 +199,16 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 #define SA_LOAD_X(dst_, row_)                                                                            \
     _Pragma("unroll") for (int T_ = 0; T_ < 2; ++T_)                                                    \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                              \
-            const s_f32x4 v_ = *reinterpret_cast<const s_f32x4*>((row_) + 32 * T_ + 8 * g_ + 4 * kh);    \
+            s_f32x4 v_ = *reinterpret_cast<const s_f32x4*>((row_) + 32 * T_ + 8 * g_ + 4 * kh);          \
+            if (abs_ != nullptr) {                                                                       \
+                const s_f32x4 A_ = *reinterpret_cast<const s_f32x4*>(abs_ + 32 * T_ + 8 * g_ + 4 * kh);  \
+                const s_f32x4 B_ = *reinterpret_cast<const s_f32x4*>(abs_ + SA_C + 32 * T_ + 8 * g_ + 4 * kh); \
+                v_ = v_ * A_ + B_;                                                                       \
+            }                                                                                            \
             _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) dst_[T_][4 * g_ + j_] = v_[j_];           \
         }
+    // (not in PAIR mode: its register budget is full, the plan keeps film_apply there)
+    const float* abs_ = (!PAIR && a.ab) ? a.ab + (size_t)b * 2 * SA_C : nullptr;
 
     // (LayerNorm 1 and its B fragments are re-made per head pair inside the loop: 32 registers that need not live
     //  through the attention phase)
@@ -401,7 +409,10 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         sa_bias(av[T], a.bo, T, kh);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const s_f32x4 v = *reinterpret_cast<const s_f32x4*>(xrow + 32 * T + 8 * g + 4 * kh);
+            s_f32x4 v = *reinterpret_cast<const s_f32x4*>(xrow + 32 * T + 8 * g + 4 * kh);
+            if (abs_ != nullptr)
+                v = v * *reinterpret_cast<const s_f32x4*>(abs_ + 32 * T + 8 * g + 4 * kh) +
+                    *reinterpret_cast<const s_f32x4*>(abs_ + SA_C + 32 * T + 8 * g + 4 * kh);
 #pragma unroll
             for (int j = 0; j < 4; ++j) av[T][4 * g + j] += v[j];
         }
@@ -455,7 +466,7 @@ bool sa_fused_supported(int L, int C) { return C == SA_C && L >= 1 && L <= 512; 
 
 hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
-                             const float* bo, const float* b1, const float* b2, hipStream_t s) {
+                             const float* bo, const float* b1, const float* b2, const float* ab, hipStream_t s) {
     if (!sa_fused_supported(L, SA_C) || B <= 0) return hipErrorInvalidValue;
     SaFusedArgs a{};
     a.x = x; a.out = out; a.L = L;
@@ -464,8 +475,9 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     a.wo_h = (const _Float16*)w_hl[2]; a.wo_l = (const _Float16*)w_hl[3];
     a.w1_h = (const _Float16*)w_hl[4]; a.w1_l = (const _Float16*)w_hl[5];
     a.w2_h = (const _Float16*)w_hl[6]; a.w2_l = (const _Float16*)w_hl[7];
-    a.bqkv = bqkv; a.bo = bo; a.b1 = b1; a.b2 = b2;
+    a.bqkv = bqkv; a.bo = bo; a.b1 = b1; a.b2 = b2; a.ab = ab;
     const bool pair = L > 256;                                                    // two workgroups per trajectory
+    if (pair && ab != nullptr) return hipErrorInvalidValue;                       // (the plan keeps film_apply there)
     const int nwave = pair ? 8 : (L + 31) / 32;
     const int Lp = pair ? 512 : nwave * 32;
     const bool wlds = !pair && (nwave >= 4) && getenv("SPDM_SA_NO_WLDS") == nullptr;      // long sequences: weights staged in LDS

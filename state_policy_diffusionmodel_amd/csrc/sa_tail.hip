@@ -42,6 +42,7 @@ struct SaTailArgs {
     int M;
     const float *wf_o, *wf_1, *wf_2;            // fragment-order split weights (128 x 128 each)
     const float *b_o, *b_1, *b_2, *ln_g, *ln_b;
+    const float* ab; int L;                     // optional [M / L][2][128]: x is y = A x + B per sample of L rows (FiLM tail folded in)
 };
 
 __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
     for (int i = 0; i < NP; ++i) {
         const int row = min(m0 + 8 * i + srow0, M - 1);
         av[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
+        if (a.ab != nullptr) {
+            const float* ab_ = a.ab + (size_t)(row / a.L) * 2 * T_C + c16 * 4;
+            av[i] = av[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + T_C);
+        }
     }
     __syncthreads();
 
@@ -228,6 +233,7 @@ struct SaQkvArgs {
     const float* x; float* qkv; int M;          // [M][128] -> [M][384]
     const float* wf;                            // fragment-order split in_proj weight (384 x 128)
     const float *b_in, *ln_g, *ln_b;
+    const float* ab; int L;                     // optional FiLM-tail coefficients, as in SaTailArgs
 };
 
 __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
@@ -258,6 +264,10 @@ __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
         for (int i = 0; i < NP; ++i) {
             const int row = min(m0 + 8 * i + srow0, M - 1);
             v[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
+            if (a.ab != nullptr) {
+                const float* ab_ = a.ab + (size_t)(row / a.L) * 2 * T_C + c16 * 4;
+                v[i] = v[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + T_C);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -316,23 +326,23 @@ bool sa_tail_supported(int C) { return C == T_C && getenv("SPDM_NO_SA_TAIL") == 
 
 hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                              const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
-                             const float* ln_b, hipStream_t s) {
-    if (rows <= 0 || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
+                             const float* ln_b, const float* ab, int L, hipStream_t s) {
+    if (rows <= 0 || (ab && L <= 0) || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
         return hipErrorInvalidValue;
     SaTailArgs a{};
     a.o = o; a.x = x; a.out = out; a.M = rows;
     a.wf_o = wf_o; a.wf_1 = wf_1; a.wf_2 = wf_2;
-    a.b_o = b_o; a.b_1 = b_1; a.b_2 = b_2; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.b_o = b_o; a.b_1 = b_1; a.b_2 = b_2; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
     const size_t lds = (size_t)4 * T_M * T_LDK * sizeof(float);          // 36.9 KB
     hipLaunchKernelGGL(sa_tail128_kernel, dim3((rows + T_M - 1) / T_M), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_sa_qkv128(const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
-                            const float* ln_b, hipStream_t s) {
-    if (rows <= 0 || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
+                            const float* ln_b, const float* ab, int L, hipStream_t s) {
+    if (rows <= 0 || (ab && L <= 0) || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
     SaQkvArgs a{};
-    a.x = x; a.qkv = qkv; a.M = rows; a.wf = wf_in; a.b_in = b_in; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.x = x; a.qkv = qkv; a.M = rows; a.wf = wf_in; a.b_in = b_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
     const size_t lds = (size_t)(4 * T_M * T_LDK + T_M * T_C) * sizeof(float);     // slab 36.9 KB + output tile 32 KB
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(sa_qkv128_kernel)); e != hipSuccess) return e;
     hipLaunchKernelGGL(sa_qkv128_kernel, dim3((rows + T_M - 1) / T_M), dim3(256), lds, s, a);

@@ -785,21 +785,24 @@ struct Ctx {
     bool sa_fused(const AttnW& w, int level) const {
         return h->split && sa_fused_supported(HWl(level), w.C) && getenv("SPDM_NO_SA_FUSED") == nullptr;
     }
-    Tensor attention(Tensor& x, StatsBuf& xs, const AttnW& w, int level) {
+    // ab (optional): x is the RAW conv output and the block input is ab-affine of it (film_coef); consumed here.
+    Tensor attention(Tensor& x, StatsBuf& xs, const AttnW& w, int level, Tensor* ab = nullptr) {
         const int L = HWl(level), rows = B * L, C = w.C;
+        const float* abp = (ab && ab->valid) ? ab->p : nullptr;
         if (sa_fused(w, level)) {            // whole block in one kernel (sa_fused.hip)
             Tensor out = talloc(C, level);
             if (!err && !dry)
                 check(launch_sa_fused64(x.p, out.p, B, L, w.ln_g, w.ln_b, w.ff_ln_g, w.ff_ln_b, w.fw, w.in_proj.b,
-                                        w.out_proj.b, w.ff1.b, w.ff2.b, s), "fused attention block");
+                                        w.out_proj.b, w.ff1.b, w.ff2.b, abp, s), "fused attention block");
             free(x);
             free(xs);
+            if (ab) free(*ab);
             return out;
         }
         Tensor qkv = ralloc(rows, 3 * C);
         if (h->split && sa_tail_supported(C) && (dry || w.qkv_wf)) {     // LayerNorm + in_proj in one 64-row kernel (sa_tail.hip)
             if (!err && !dry)
-                check(launch_sa_qkv128(x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, s), "attention in_proj");
+                check(launch_sa_qkv128(x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s), "attention in_proj");
         } else {
             linear(x.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr, &xs, w.ln_g, w.ln_b);
         }
@@ -812,9 +815,10 @@ struct Ctx {
             Tensor out = talloc(C, level);
             if (!err && !dry)
                 check(launch_sa_tail128(att.p, x.p, out.p, rows, w.tail_wf[0], w.tail_wf[1], w.tail_wf[2], w.out_proj.b, w.ff1.b,
-                                        w.ff2.b, w.ff_ln_g, w.ff_ln_b, s), "attention tail");
+                                        w.ff2.b, w.ff_ln_g, w.ff_ln_b, abp, L, s), "attention tail");
             free(att);
             free(x);
+            if (ab) free(*ab);
             return out;
         }
         Tensor av = talloc(C, level);
@@ -831,6 +835,25 @@ struct Ctx {
         free(f1);
         free(av);
         return out;
+    }
+    // May the FiLM tail feeding this attention block be folded into the block's loads?  Only the kernels that read the
+    // block input themselves take the coefficients: sa_fused64 and the C = 128 pair sa_qkv128 / sa_tail128.
+    bool film_foldable(const AttnW& w, int level) const {
+        if (!h->cfg.attention || h->arena.keep || !h->split || getenv("SPDM_NO_FILM_FOLD") != nullptr) return false;
+        if (sa_fused(w, level)) return HWl(level) <= 256;      // (the two-workgroup mode for longer sequences has no registers left)
+        return sa_tail_supported(w.C) && (dry || (w.qkv_wf && w.tail_wf[0]));
+    }
+    // the FiLM tail as coefficients (film_coef_kernel): returns the RAW conv tensor of v (its statistics are released),
+    // *ab receives [B][2 C]
+    Tensor film_coef(Value& v, const ResampleW& w, int blk, bool use_cond, Tensor* ab) {
+        *ab = ralloc(B, 2 * w.cout);
+        if (!err && !dry)
+            check(launch_film_coef(asrc(v), w.temb_table, h->d_t, (h_tcount), (use_cond && h->cfg.cond_dim > 0) ? h->d_film[blk] : nullptr,
+                                   ab->p, B, s), "film_coef");
+        Tensor raw = v.t;
+        v.t.valid = false;
+        free(v);
+        return raw;
     }
     // tail of DownSample/UpSample.forward: + time embedding, FiLM.  Consumes v.
     Tensor film_tail(Value& v, const ResampleW& w, int blk, int level, bool use_cond, StatsBuf* row_stats) {
@@ -883,10 +906,15 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         Value b2 = c.double_conv(a, h->down[i].dc2, lout);
         c.prof_end();
         StatsBuf ys;
-        Tensor y = c.film_tail(b2, h->down[i], i, lout, use_cond,
-                               (h->cfg.attention && !c.sa_fused(h->sa[i], lout)) ? &ys : nullptr);
-        c.tap(dn[i], y);
-        if (h->cfg.attention) y = c.attention(y, ys, h->sa[i], lout);
+        Tensor y, ab;
+        if (c.film_foldable(h->sa[i], lout)) {
+            y = c.film_coef(b2, h->down[i], i, use_cond, &ab);
+        } else {
+            y = c.film_tail(b2, h->down[i], i, lout, use_cond,
+                            (h->cfg.attention && !c.sa_fused(h->sa[i], lout)) ? &ys : nullptr);
+            c.tap(dn[i], y);
+        }
+        if (h->cfg.attention) y = c.attention(y, ys, h->sa[i], lout, &ab);
         c.tap(xn[i], y);
         Value nv;
         nv.t = y;
@@ -922,10 +950,15 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
         Value b3 = c.double_conv(a, h->up[i].dc2, lout);
         c.prof_end();
         StatsBuf ys;
-        Tensor y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond,
-                               (h->cfg.attention && !c.sa_fused(h->sa[3 + i], lout)) ? &ys : nullptr);
-        c.tap(un[i], y);
-        if (h->cfg.attention) y = c.attention(y, ys, h->sa[3 + i], lout);
+        Tensor y, ab;
+        if (c.film_foldable(h->sa[3 + i], lout)) {
+            y = c.film_coef(b3, h->up[i], 3 + i, use_cond, &ab);
+        } else {
+            y = c.film_tail(b3, h->up[i], 3 + i, lout, use_cond,
+                            (h->cfg.attention && !c.sa_fused(h->sa[3 + i], lout)) ? &ys : nullptr);
+            c.tap(un[i], y);
+        }
+        if (h->cfg.attention) y = c.attention(y, ys, h->sa[3 + i], lout, &ab);
         c.tap(an[i], y);
         Value nv;
         nv.t = y;
@@ -1122,7 +1155,7 @@ extern "C" int spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_
         key.sched_kind = h->sched_kind; key.n_steps = h->n_steps; key.inpaint = h->s_inpaint; key.noise = h->s_noise;
         key.history = h->s_history; key.seed = h->s_seed; key.offset = h->s_offset;
         {   // the captured launches depend on the kernel-selection switches too (tests flip them inside one process)
-            static const char* const sw[] = {"SPDM_ATTN_VALU", "SPDM_NO_SA_FUSED", "SPDM_NO_SA_TAIL", "SPDM_NO_T512", "SPDM_NO_W2",
+            static const char* const sw[] = {"SPDM_ATTN_VALU", "SPDM_NO_FILM_FOLD", "SPDM_NO_SA_FUSED", "SPDM_NO_SA_TAIL", "SPDM_NO_T512", "SPDM_NO_W2",
                                              "SPDM_NO_WIDE", "SPDM_NO_WIDE128", "SPDM_SA_NO_WLDS", "SPDM_T3_BIG", "SPDM_T512",
                                              "SPDM_WIDE_N64_2X2"};
             for (unsigned k = 0; k < sizeof(sw) / sizeof(sw[0]); ++k)

@@ -91,13 +91,14 @@ def test_both_contraction_paths_match_golden(exact):
 
 
 def test_unfused_fallbacks_match_fused_paths(monkeypatch):
-    """The fused SelfAttention kernel / MFMA attention / zero-tap skipping each have a plain fallback
+    """The fused SelfAttention kernels / MFMA attention / zero-tap skipping / FiLM fold / wide conv each have a plain fallback
     (env switches); all must agree with the default build on the same input to fp32 rounding."""
     g = np.load(os.path.join(GOLDEN, "unet_h32d3_b2.npz"))
     sd = weights(1350, 0, True, str(g["weights_sha256"]))
     x, cond = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["cond"]).cuda()
     outs = []
-    for env in ({}, {"SPDM_NO_SA_FUSED": "1"}, {"SPDM_NO_SA_FUSED": "1", "SPDM_ATTN_VALU": "1"}, {"SPDM_NO_W2": "1", "SPDM_NO_T512": "1"}):
+    for env in ({}, {"SPDM_NO_SA_FUSED": "1"}, {"SPDM_NO_SA_FUSED": "1", "SPDM_ATTN_VALU": "1"}, {"SPDM_NO_W2": "1", "SPDM_NO_T512": "1"},
+                {"SPDM_NO_FILM_FOLD": "1"}, {"SPDM_NO_SA_TAIL": "1"}, {"SPDM_NO_WIDE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = make_engine(32, 3, 1350, 2, sd, True)
