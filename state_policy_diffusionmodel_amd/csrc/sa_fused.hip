@@ -200,15 +200,22 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     _Pragma("unroll") for (int T_ = 0; T_ < 2; ++T_)                                                    \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                              \
             s_f32x4 v_ = *reinterpret_cast<const s_f32x4*>((row_) + 32 * T_ + 8 * g_ + 4 * kh);          \
-            if (abs_ != nullptr) {                                                                       \
-                const s_f32x4 A_ = *reinterpret_cast<const s_f32x4*>(abs_ + 32 * T_ + 8 * g_ + 4 * kh);  \
-                const s_f32x4 B_ = *reinterpret_cast<const s_f32x4*>(abs_ + SA_C + 32 * T_ + 8 * g_ + 4 * kh); \
+            if (fold) {                                                                                  \
+                const s_f32x4 A_ = *reinterpret_cast<const s_f32x4*>(ab_s + 32 * T_ + 8 * g_ + 4 * kh); \
+                const s_f32x4 B_ = *reinterpret_cast<const s_f32x4*>(ab_s + SA_C + 32 * T_ + 8 * g_ + 4 * kh); \
                 v_ = v_ * A_ + B_;                                                                       \
             }                                                                                            \
             _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) dst_[T_][4 * g_ + j_] = v_[j_];           \
         }
+    // FiLM tail folded into the load (film_coef_kernel): the sample's [A | B] sits in LDS, every x load applies it.
     // (not in PAIR mode: its register budget is full, the plan keeps film_apply there)
-    const float* abs_ = (!PAIR && a.ab) ? a.ab + (size_t)b * 2 * SA_C : nullptr;
+    float* ab_s = reinterpret_cast<float*>(WLDS ? Wsl + (size_t)256 * SA_WROW : Wsh);     // behind the last array in use
+    const bool fold = !PAIR && a.ab != nullptr;
+    if (fold) {
+        if (tid < 2 * SA_C / 4)
+            *reinterpret_cast<s_f32x4*>(ab_s + 4 * tid) = *reinterpret_cast<const s_f32x4*>(a.ab + (size_t)b * 2 * SA_C + 4 * tid);
+        __syncthreads();
+    }
 
     // (LayerNorm 1 and its B fragments are re-made per head pair inside the loop: 32 registers that need not live
     //  through the attention phase)
@@ -410,9 +417,9 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             s_f32x4 v = *reinterpret_cast<const s_f32x4*>(xrow + 32 * T + 8 * g + 4 * kh);
-            if (abs_ != nullptr)
-                v = v * *reinterpret_cast<const s_f32x4*>(abs_ + 32 * T + 8 * g + 4 * kh) +
-                    *reinterpret_cast<const s_f32x4*>(abs_ + SA_C + 32 * T + 8 * g + 4 * kh);
+            if (fold)
+                v = v * *reinterpret_cast<const s_f32x4*>(ab_s + 32 * T + 8 * g + 4 * kh) +
+                    *reinterpret_cast<const s_f32x4*>(ab_s + SA_C + 32 * T + 8 * g + 4 * kh);
 #pragma unroll
             for (int j = 0; j < 4; ++j) av[T][4 * g + j] += v[j];
         }
@@ -481,7 +488,8 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     const int nwave = pair ? 8 : (L + 31) / 32;
     const int Lp = pair ? 512 : nwave * 32;
     const bool wlds = !pair && (nwave >= 4) && getenv("SPDM_SA_NO_WLDS") == nullptr;      // long sequences: weights staged in LDS
-    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16);
+    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16) +
+                       2 * SA_C * sizeof(float);                                               // + the FiLM-coefficient row
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool full = (L % 32 == 0);
     void (*kern)(const SaFusedArgs) =

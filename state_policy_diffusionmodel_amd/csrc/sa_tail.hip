@@ -59,6 +59,24 @@ __device__ __forceinline__ float thalf_sum(float v) {
     return v;
 }
 
+// FiLM tail folded into the load of the block input (film_coef_kernel): piece i (rows m0 + 8 i .. + 7, columns 4 c16 ..)
+// becomes A x + B with the coefficients of its sample.  L % 8 == 0, so a piece never straddles two samples and the sample
+// index is wave-uniform; when the whole 64-row tile lies in one sample the coefficients are loaded once.
+__device__ __forceinline__ void tail_film_fold(tf32x4 (&v)[8], const float* __restrict__ ab, int L, int m0, int M, int c16) {
+    if (L % T_M == 0) {
+        const float* ab_ = ab + (size_t)(m0 / L) * 2 * T_C + c16 * 4;
+        const tf32x4 A = *reinterpret_cast<const tf32x4*>(ab_), B = *reinterpret_cast<const tf32x4*>(ab_ + T_C);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * A + B;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* ab_ = ab + (size_t)(min(m0 + 8 * i, M - 1) / L) * 2 * T_C + c16 * 4;
+            v[i] = v[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + T_C);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) {
     constexpr int RT = 2, CT = 4;                       // per wave: 32 rows x 64 columns = 2 x 4 tiles of 16 x 16
     constexpr int NP = T_M / 8;                         // row pieces per thread
@@ -153,11 +171,8 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
     for (int i = 0; i < NP; ++i) {
         const int row = min(m0 + 8 * i + srow0, M - 1);
         av[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
-        if (a.ab != nullptr) {
-            const float* ab_ = a.ab + (size_t)(row / a.L) * 2 * T_C + c16 * 4;
-            av[i] = av[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + T_C);
-        }
     }
+    if (a.ab != nullptr) tail_film_fold(av, a.ab, a.L, m0, M, c16);
     __syncthreads();
 
     tf32x4 acc[RT][CT];
@@ -264,11 +279,8 @@ __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
         for (int i = 0; i < NP; ++i) {
             const int row = min(m0 + 8 * i + srow0, M - 1);
             v[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
-            if (a.ab != nullptr) {
-                const float* ab_ = a.ab + (size_t)(row / a.L) * 2 * T_C + c16 * 4;
-                v[i] = v[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + T_C);
-            }
         }
+        if (a.ab != nullptr) tail_film_fold(v, a.ab, a.L, m0, M, c16);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const tf32x4 t = v[i];
@@ -327,7 +339,7 @@ bool sa_tail_supported(int C) { return C == T_C && getenv("SPDM_NO_SA_TAIL") == 
 hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                              const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
                              const float* ln_b, const float* ab, int L, hipStream_t s) {
-    if (rows <= 0 || (ab && L <= 0) || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
+    if (rows <= 0 || (ab && (L <= 0 || L % 8 != 0)) || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
         return hipErrorInvalidValue;
     SaTailArgs a{};
     a.o = o; a.x = x; a.out = out; a.M = rows;
@@ -340,7 +352,7 @@ hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int row
 
 hipError_t launch_sa_qkv128(const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
                             const float* ln_b, const float* ab, int L, hipStream_t s) {
-    if (rows <= 0 || (ab && L <= 0) || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
+    if (rows <= 0 || (ab && (L <= 0 || L % 8 != 0)) || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
     SaQkvArgs a{};
     a.x = x; a.qkv = qkv; a.M = rows; a.wf = wf_in; a.b_in = b_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
     const size_t lds = (size_t)(4 * T_M * T_LDK + T_M * T_C) * sizeof(float);     // slab 36.9 KB + output tile 32 KB

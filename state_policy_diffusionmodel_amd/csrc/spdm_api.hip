@@ -841,7 +841,7 @@ struct Ctx {
     bool film_foldable(const AttnW& w, int level) const {
         if (!h->cfg.attention || h->arena.keep || !h->split || getenv("SPDM_NO_FILM_FOLD") != nullptr) return false;
         if (sa_fused(w, level)) return HWl(level) <= 256;      // (the two-workgroup mode for longer sequences has no registers left)
-        return sa_tail_supported(w.C) && (dry || (w.qkv_wf && w.tail_wf[0]));
+        return sa_tail_supported(w.C) && HWl(level) % 8 == 0 && (dry || (w.qkv_wf && w.tail_wf[0]));
     }
     // the FiLM tail as coefficients (film_coef_kernel): returns the RAW conv tensor of v (its statistics are released),
     // *ab receives [B][2 C]
