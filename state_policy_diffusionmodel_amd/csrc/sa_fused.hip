@@ -41,7 +41,7 @@ constexpr float SA_DESCALE = 1.0f / 2048.0f;      // act x16, weight x128
 struct SaFusedArgs {
     const float* x; float* out; int L;
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-    const _Float16 *wqkv_h, *wqkv_l, *wo_h, *wo_l, *w1_h, *w1_l, *w2_h, *w2_l;   // [rows][64], permuted, x128
+    const _Float16 *wqkv_h, *wqkv_l, *wo_h, *wo_l, *w1_h, *w1_l, *w2_h, *w2_l;   // [rows][64] permuted, x128, in fragment order
     const float *bqkv, *bo, *b1, *b2;
     const float* ab;       // optional [B][2][64]: the block input is y = A x + B per sample (FiLM tail folded into the load)
 };
@@ -72,12 +72,14 @@ __device__ __forceinline__ void sa_make_frags(const s_f32x16 (&z)[2], s_f16x8 (&
 // acc (+)= W[row0 + li][0..63] . B   (one 32-row output tile, K = 64 = 4 k-steps)
 __device__ __forceinline__ s_f32x16 sa_gemm_tile(const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, int row0,
                                                   int li, int kh, const s_f16x8 (&bh)[4], const s_f16x8 (&bl)[4], s_f32x16 acc) {
-    const _Float16* ph = Wh + (size_t)(row0 + li) * SA_C + 8 * kh;
-    const _Float16* pl = Wl + (size_t)(row0 + li) * SA_C + 8 * kh;
+    // fragment order (spdm_api.hip perm_split): block (row0 / 32) * 4 + ks holds, for lane kh * 32 + li, the 8 halfs
+    // W[row0 + li][16 ks + 8 kh ..] -- one contiguous 1 KiB per wave load
+    const _Float16* ph = Wh + ((size_t)(row0 >> 5) * 256 + 32 * kh + li) * 8;
+    const _Float16* pl = Wl + ((size_t)(row0 >> 5) * 256 + 32 * kh + li) * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const s_f16x8 ah = *reinterpret_cast<const s_f16x8*>(ph + 16 * ks);
-        const s_f16x8 al = *reinterpret_cast<const s_f16x8*>(pl + 16 * ks);
+        const s_f16x8 ah = *reinterpret_cast<const s_f16x8*>(ph + 512 * ks);
+        const s_f16x8 al = *reinterpret_cast<const s_f16x8*>(pl + 512 * ks);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
@@ -102,9 +104,11 @@ __device__ __forceinline__ s_f32x16 sa_gemm_tile_lds(const _Float16* Wh, const _
 }
 // cooperative copy of nrows weight rows (64 halfs each) global -> LDS rows dst_row0.. (16 bytes per thread per step)
 __device__ __forceinline__ void sa_stage_rows(_Float16* dst, int dst_row0, const _Float16* __restrict__ src, int nrows, int tid, int nthr) {
+    // (the source is in fragment order: unit i = block (rt, ks), lane (kh, li) -> row 32 rt + li, halfs 16 ks + 8 kh ..)
     for (int i = tid; i < nrows * 8; i += nthr) {
-        const int r = i >> 3, c = i & 7;
-        *reinterpret_cast<s_f16x8*>(dst + (dst_row0 + r) * SA_WROW + 8 * c) = *reinterpret_cast<const s_f16x8*>(src + (size_t)r * SA_C + 8 * c);
+        const int blk = i >> 6, ln = i & 63;
+        const int r = 32 * (blk >> 2) + (ln & 31), c = 2 * (blk & 3) + (ln >> 5);
+        *reinterpret_cast<s_f16x8*>(dst + (dst_row0 + r) * SA_WROW + 8 * c) = *reinterpret_cast<const s_f16x8*>(src + (size_t)i * 8);
     }
 }
 // z[T][r] -> z * DESCALE + bias[feature]   (feature of register r in tile T: 32 T + (r&3) + 8 (r>>2) + 4 kh)
@@ -400,9 +404,9 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 const s_f16x8 ah = WLDS ? *reinterpret_cast<const s_f16x8*>(Wsh + (192 + 32 * T + li) * SA_WROW + 16 * head + 8 * kh)
-                                        : *reinterpret_cast<const s_f16x8*>(a.wo_h + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
+                                        : *reinterpret_cast<const s_f16x8*>(a.wo_h + ((size_t)(4 * T + head) * 64 + 32 * kh + li) * 8);
                 const s_f16x8 al = WLDS ? *reinterpret_cast<const s_f16x8*>(Wsl + (192 + 32 * T + li) * SA_WROW + 16 * head + 8 * kh)
-                                        : *reinterpret_cast<const s_f16x8*>(a.wo_l + (size_t)(32 * T + li) * SA_C + 16 * head + 8 * kh);
+                                        : *reinterpret_cast<const s_f16x8*>(a.wo_l + ((size_t)(4 * T + head) * 64 + 32 * kh + li) * 8);
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, o_h, av[T], 0, 0, 0);
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, o_l, av[T], 0, 0, 0);
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, o_h, av[T], 0, 0, 0);

@@ -467,7 +467,7 @@ struct Loader {
         r.cout = cout;
         return r;
     }
-    // (out, 64) fp32 -> two fp16 arrays [out][64] (hi, lo of 128 x), input axis permuted inside each group of 16 by
+    // (out, 64) fp32 -> two fp16 arrays (hi, lo of 128 x) of [out][64] in fragment order, input axis permuted inside each group of 16 by
     // perm16 = 0 1 2 3 8 9 10 11 | 4 5 6 7 12 13 14 15: the k-slot order of an accumulator tile used as B operand
     // (sa_fused.hip)
     void perm_split(const std::string& wname, int out, void** hi_dev, void** lo_dev) {
@@ -483,6 +483,18 @@ struct Loader {
                     hi[(size_t)o * 64 + 16 * g + pos] = h16;
                     lo[(size_t)o * 64 + 16 * g + pos] = (_Float16)(x - (float)h16);
                 }
+        // device layout = MFMA A-fragment order: block (o / 32) * 4 + ks, lane kh * 32 + o % 32 -> halfs [o][16 ks + 8 kh ..]
+        auto to_frag = [&](const std::vector<_Float16>& rm) {
+            std::vector<_Float16> f(rm.size());
+            for (int o = 0; o < out; ++o)
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int kh = 0; kh < 2; ++kh)
+                        for (int j = 0; j < 8; ++j)
+                            f[((((size_t)(o / 32) * 4 + ks) * 64) + kh * 32 + o % 32) * 8 + j] = rm[(size_t)o * 64 + 16 * ks + 8 * kh + j];
+            return f;
+        };
+        hi = to_frag(hi);
+        lo = to_frag(lo);
         for (int which = 0; which < 2; ++which) {
             void* d = nullptr;
             const std::vector<_Float16>& src = which ? lo : hi;
