@@ -340,6 +340,7 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
         hipError_t e = hipMalloc((void**)&h->arena.base, h->arena.cap);
         if (e != hipSuccess) { rc = fail(SPDM_ERR_NOMEM, "workspace of %zu bytes: %s", h->arena.cap, hipGetErrorString(e)); break; }
         h->owned.push_back(h->arena.base);
+        if (getenv("SPDM_ARENA_TRACE")) fprintf(stderr, "[spdm] arena %p, %zu MiB\n", (void*)h->arena.base, h->arena.cap >> 20);
     } while (0);
     if (rc) { spdm_destroy(h); return rc; }
     default_time_table(h->time_table, cfg->num_train_timesteps, cfg->time_dim);
@@ -660,6 +661,7 @@ struct Ctx {
             return t;
         }
         t.off = off; t.p = (float*)(h->arena.base + off); t.valid = true;
+        if (!dry && getenv("SPDM_ARENA_TRACE")) fprintf(stderr, "[spdm] level %d C %3d at %8.2f MiB (%.1f MiB)\n", level, C, off / 1048576.0, (double)B * HWl(level) * C * 4 / 1048576.0);
         return t;
     }
     Tensor ralloc(int rows, int C) {       // [rows][C] scratch (attention path)
