@@ -188,6 +188,17 @@ int  spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, int32_t Ci
                                         GroupNorm mean (in sigmas) / variance (relative) the launch reported from the
                                         values recomputed from its own output (both: debug == 0, else -1) */);
 
+/* Observation front end (widened scope).  Replaces: self.vision_encoder(img.flatten(end_dim=1))
+ * in prepare_obs_cond_vectors (models/diffusion_ddpm.py:317-321), i.e. Autoencoder.encoder of
+ * models/encoder/autoencoder.py:11-20: Conv2d(3,16,2,2,p1) ReLU Conv2d(16,32,2,2) ReLU Conv2d(32,64,2,2) ReLU Flatten
+ * Linear(9216,128).  Weights: the encoder's own state_dict (names "0.weight" "0.bias" "2.*" "4.*" "7.*", torch layouts)
+ * as a host blob + index, like spdm_load_weights.  d_images: (n,3,96,96) fp32 on the device; d_latent: (n,128). */
+typedef struct spdm_encoder spdm_encoder;
+int  spdm_encoder_create(int32_t device, const float* h_blob, size_t n_floats, const spdm_tensor_index* h_index,
+                         int32_t n_index, spdm_encoder** out);
+int  spdm_encoder_forward(spdm_encoder* e, int32_t n_images, const float* d_images, float* d_latent, void* stream);
+void spdm_encoder_destroy(spdm_encoder* e);
+
 /* Op-level test hook: d_y = GELU(d_x) evaluated with the device erf that the conv prologues use
  * (nn.GELU(), models/Unet_FiLmLayer.py:104). */
 int  spdm_op_gelu(const float* d_x, float* d_y, size_t n, void* stream);

@@ -46,6 +46,9 @@ SYMBOLS = {
     "spdm_device_bytes": (c_size_t, [c_void_p]),
     "spdm_profile_enable": (c_int32, [c_void_p, c_int32]),
     "spdm_profile_read": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+    "spdm_encoder_create": (c_int32, [c_int32, c_void_p, c_size_t, POINTER(TensorIndex), c_int32, POINTER(c_void_p)]),
+    "spdm_encoder_forward": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "spdm_encoder_destroy": (None, [c_void_p]),
     "spdm_op_gelu": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "spdm_bench_gemm": (c_int32, [c_int32] * 12 + [POINTER(c_double)]),   # ms_out[2]: {ms per launch, max|split - fp32|}
 }

@@ -122,6 +122,10 @@ hipError_t launch_film_apply(const AffineSrc& src, const float* temb_table /*[T]
 // the same tail as per-(sample, channel) coefficients ab[b] = [A (C) | B (C)], y = A x + B, for consumers that apply it on load
 hipError_t launch_film_coef(const AffineSrc& src, const float* temb_table, const int* t_dev, int t_count, const float* film,
                             float* ab, int B, hipStream_t s);
+// encoder.hip: the three stride-2 2x2 convolutions (+ReLU) of the observation autoencoder's encoder
+// (models/encoder/autoencoder.py:11-17), (n,3,96,96) -> flattened (n, 64*12*12) rows for its Linear layer
+hipError_t launch_encoder_convs(const float* img, const float* w1, const float* b1, const float* w2, const float* b2,
+                                const float* w3, const float* b3, float* feat, int n_images, hipStream_t s);
 // plain GN apply (materialise): y = GN(x)
 hipError_t launch_gn_apply(const AffineSrc& src, float* dst, int B, int HW, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int C,

@@ -1412,6 +1412,88 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     return SPDM_OK;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Observation front end: the autoencoder's encoder, models/encoder/autoencoder.py:11-20, applied by
+// prepare_obs_cond_vectors (models/diffusion_ddpm.py:317-321) to every observed frame once per sample() call.
+struct spdm_encoder {
+    int device = 0;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr, *wl = nullptr, *bl = nullptr;
+    float* feat = nullptr;            // [chunk][9216] flattened conv-3 maps of the chunk in flight
+    int chunk = 0;
+    std::vector<void*> owned;
+};
+static constexpr int ENC_FEAT = 64 * 12 * 12, ENC_LATENT = 128, ENC_CHUNK = 2048;
+
+extern "C" void spdm_encoder_destroy(spdm_encoder* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (void* p : e->owned) (void)hipFree(p);
+    delete e;
+}
+
+extern "C" int spdm_encoder_create(int32_t device, const float* blob, size_t n, const spdm_tensor_index* index, int32_t n_index,
+                                   spdm_encoder** out) {
+    if (!blob || !index || n_index <= 0 || !out) return fail(SPDM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    Loader L{nullptr, blob, n};
+    for (int i = 0; i < n_index; ++i) {
+        char name[SPDM_NAME_MAX + 1];
+        memcpy(name, index[i].name, SPDM_NAME_MAX);
+        name[SPDM_NAME_MAX] = 0;
+        L.idx[name] = &index[i];
+    }
+    // nn.Sequential indices of Autoencoder.encoder: 0, 2, 4 = Conv2d; 7 = Linear
+    struct Item { const char* name; std::initializer_list<int> shape; float* spdm_encoder::*dst; };
+    const Item items[8] = {{"0.weight", {16, 3, 2, 2}, &spdm_encoder::w1}, {"0.bias", {16}, &spdm_encoder::b1},
+                           {"2.weight", {32, 16, 2, 2}, &spdm_encoder::w2}, {"2.bias", {32}, &spdm_encoder::b2},
+                           {"4.weight", {64, 32, 2, 2}, &spdm_encoder::w3}, {"4.bias", {64}, &spdm_encoder::b3},
+                           {"7.weight", {ENC_LATENT, ENC_FEAT}, &spdm_encoder::wl}, {"7.bias", {ENC_LATENT}, &spdm_encoder::bl}};
+    spdm_encoder* e = new spdm_encoder();
+    e->device = device;
+    for (const Item& it : items) {
+        const float* src = L.find(it.name, it.shape);
+        if (!src) { spdm_encoder_destroy(e); return L.err; }
+        size_t numel = 1;
+        for (int d : it.shape) numel *= (size_t)d;
+        void* p = nullptr;
+        if (hipMalloc(&p, numel * sizeof(float)) != hipSuccess || hipMemcpy(p, src, numel * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            if (p) (void)hipFree(p);
+            spdm_encoder_destroy(e);
+            return fail(SPDM_ERR_HIP, "encoder weight upload failed");
+        }
+        e->owned.push_back(p);
+        e->*(it.dst) = (float*)p;
+    }
+    *out = e;
+    return SPDM_OK;
+}
+
+extern "C" int spdm_encoder_forward(spdm_encoder* e, int32_t n_images, const float* d_images, float* d_latent, void* stream) {
+    if (!e || !d_images || !d_latent || n_images <= 0) return fail(SPDM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = std::min<int>(n_images, ENC_CHUNK);
+    if (e->chunk < chunk) {             // (grown lazily; the old buffer stays owned until destroy: at most two sizes ever exist)
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, sizeof(float) * (size_t)chunk * ENC_FEAT));
+        e->owned.push_back(p);
+        e->feat = (float*)p;
+        e->chunk = chunk;
+    }
+    for (int i0 = 0; i0 < n_images; i0 += chunk) {
+        const int m = std::min(chunk, n_images - i0);
+        HIP_TRY(launch_encoder_convs(d_images + (size_t)i0 * 3 * 96 * 96, e->w1, e->b1, e->w2, e->b2, e->w3, e->b3, e->feat, m, s));
+        GemmArgs a{};                   // Linear(9216, 128) on the exact fp32 MFMA path
+        a.split = 0;
+        a.src = e->feat; a.src_ld = ENC_FEAT; a.wgt = e->wl; a.dst = d_latent + (size_t)i0 * ENC_LATENT; a.dst_ld = ENC_LATENT;
+        a.M = m; a.K = ENC_FEAT; a.N = ENC_LATENT; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
+        a.pro = PRO_NONE; a.epi = EPI_BIAS; a.bias = e->bl;
+        HIP_TRY(launch_gemm(a, s));
+    }
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return SPDM_OK;
+}
+
 // op-level test hook: y = GELU(x) with the device's own erf (the one every conv prologue uses)
 extern "C" int spdm_op_gelu(const float* d_x, float* d_y, size_t n, void* stream) {
     if (!d_x || !d_y || n == 0) return fail(SPDM_ERR_INVALID, "bad argument");

@@ -72,7 +72,8 @@ class Diffusion_DDPM:
                  observation_dim: int = 2, prediction_dim: int = 2, learning_rate: float = 1e-4,
                  model: str = "UNet", vision_encoder: Optional[Callable] = None,
                  noise_scheduler_type: str = "linear", inpaint_horizon: int = 10, step_size: int = 1,
-                 *, state_dict=None, weight_seed: int = 0, device: int = 0, max_batch: int = 1):
+                 *, state_dict=None, weight_seed: int = 0, device: int = 0, max_batch: int = 1,
+                 vision_encoder_state_dict=None):
         # --- Diffusion params (models/diffusion_ddpm.py:42-48)
         self.noise_steps = noise_steps
         self.obs_horizon = obs_horizon
@@ -96,9 +97,12 @@ class Diffusion_DDPM:
         if state_dict is None:   # random-init, like constructing the reference module without a checkpoint
             state_dict = random_state_dict(self.cond_dim, seed=weight_seed, attention=self.attention)
         self.noise_estimator = NoiseEstimator(self, state_dict)
-        # the reference loads a private autoencoder checkpoint here (:85); any callable
-        # (N,3,96,96) -> (N,128) can be plugged in, or the batch may carry 'image_features'
+        # the reference loads a private autoencoder checkpoint here (:84-88).  Given that encoder's tensors
+        # (vision_encoder_state_dict: keys 0.weight .. 7.bias, as in the diffusion checkpoint's 'vision_encoder.*'), the
+        # front end runs in libspdm_hip.so (vision.VisionEncoder, built on first use); any other callable
+        # (N,3,96,96) -> (N,128) can be plugged in instead, or the batch may carry 'image_features'
         self.vision_encoder = vision_encoder
+        self._vision_sd = vision_encoder_state_dict
         self.device = torch.device("cuda", device)
         self._device_index = device
         self._max_batch = max_batch
@@ -113,18 +117,22 @@ class Diffusion_DDPM:
     def load_from_checkpoint(cls, checkpoint_path, hparams_file=None, map_location=None, **kwargs):
         """Lightning's ``LightningModule.load_from_checkpoint(ckpt, hparams_file=yaml)`` as generate.py:25,27 and
         run_predictions.py call it: constructor arguments from ``hparams.yaml`` (``save_hyperparameters()`` of
-        models/diffusion_ddpm.py:37), U-Net tensors from the checkpoint's ``noise_estimator.*`` entries.  The vision
-        encoder's tensors are not consumed here (the front end is a pluggable callable)."""
+        models/diffusion_ddpm.py:37), U-Net tensors from the checkpoint's ``noise_estimator.*`` entries, the observation
+        encoder's from its ``vision_encoder.*`` entries when present (vision.VisionEncoder)."""
         from .weights import check_state_dict, fetch_hyperparams_from_yaml, load_checkpoint_state_dict
         hp = dict(fetch_hyperparams_from_yaml(hparams_file)) if hparams_file else {}
         ctor = {k: hp[k] for k in cls._HPARAM_KEYS if k in hp}
         if isinstance(hp.get("vision_encoder"), str) or hp.get("vision_encoder") is None:
             pass                                   # a name (e.g. 'resnet18') in the yaml is not a callable: ignored
         ctor.update(kwargs)
-        sd, _other = load_checkpoint_state_dict(str(checkpoint_path))
+        sd, other = load_checkpoint_state_dict(str(checkpoint_path))
         attention = ctor.get("model", "UNet") != "UNet_FilmnoAttention"
         cond_dim = int(ctor.get("observation_dim", 2)) * int(ctor.get("obs_horizon", 10))
         check_state_dict(sd, cond_dim, attention=attention)
+        if "vision_encoder_state_dict" not in ctor and any(k.startswith("vision_encoder.") for k in other):
+            from .vision import encoder_state_dict_from
+            from .weights import safe_load_state_dict
+            ctor["vision_encoder_state_dict"] = encoder_state_dict_from(safe_load_state_dict(str(checkpoint_path)))
         return cls(state_dict=sd, **ctor)
 
     # Lightning look-alikes used by callers (generate.py:36)
@@ -196,9 +204,12 @@ class Diffusion_DDPM:
         if "image_features" in observation_batch:
             feats = observation_batch["image_features"]
         else:
+            if self.vision_encoder is None and self._vision_sd is not None:
+                from .vision import VisionEncoder
+                self.vision_encoder = VisionEncoder(self._vision_sd, device=self._device_index)
             if self.vision_encoder is None:
-                raise RuntimeError("batch has raw images but no vision_encoder was supplied "
-                                   "(the reference's autoencoder checkpoint is not part of the repo)")
+                raise RuntimeError("batch has raw images but neither vision_encoder nor vision_encoder_state_dict was "
+                                   "supplied (the reference's autoencoder checkpoint is not part of the repo)")
             img = observation_batch["image"]
             with torch.no_grad():
                 enc = self.vision_encoder(img.flatten(end_dim=1))

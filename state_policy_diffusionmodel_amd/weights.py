@@ -202,13 +202,9 @@ def fetch_hyperparams_from_yaml(file_path: str) -> dict:
         return yaml.safe_load(fh) or {}
 
 
-def load_checkpoint_state_dict(checkpoint_path: str, prefix: str = "noise_estimator."):
-    """The U-Net tensors of a reference checkpoint (Lightning ``.ckpt``: ``{'state_dict': {'noise_estimator.*': ...,
-    'vision_encoder.*': ...}, ...}``; generate.py:23-26 reads it through ``load_from_checkpoint``), or of a bare
-    ``state_dict`` file, with the ``noise_estimator.`` prefix removed.
-
-    Only loaders that execute nothing from the file are used (``torch.load(weights_only=True)``); a checkpoint the
-    safe loader refuses is reported, never unpickled.  Returns ``(unet_state_dict, other_keys)``."""
+def safe_load_state_dict(checkpoint_path: str):
+    """The full ``state_dict`` of a Lightning ``.ckpt`` (or a bare state_dict file), read with
+    ``torch.load(weights_only=True)`` only: a file the safe loader refuses is reported, never unpickled."""
     import torch
     try:
         ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
@@ -218,6 +214,17 @@ def load_checkpoint_state_dict(checkpoint_path: str, prefix: str = "noise_estima
     sd = ck.get("state_dict", ck) if isinstance(ck, dict) else None
     if not isinstance(sd, dict) or not sd:
         raise RuntimeError(f"{checkpoint_path}: no state_dict found")
+    return sd
+
+
+def load_checkpoint_state_dict(checkpoint_path: str, prefix: str = "noise_estimator."):
+    """The U-Net tensors of a reference checkpoint (Lightning ``.ckpt``: ``{'state_dict': {'noise_estimator.*': ...,
+    'vision_encoder.*': ...}, ...}``; generate.py:23-26 reads it through ``load_from_checkpoint``), or of a bare
+    ``state_dict`` file, with the ``noise_estimator.`` prefix removed.
+
+    Only loaders that execute nothing from the file are used (``torch.load(weights_only=True)``); a checkpoint the
+    safe loader refuses is reported, never unpickled.  Returns ``(unet_state_dict, other_keys)``."""
+    sd = safe_load_state_dict(checkpoint_path)
     unet, other = OrderedDict(), []
     has_prefix = any(k.startswith(prefix) for k in sd)
     for k, v in sd.items():
