@@ -10,7 +10,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 from .weights import TensorIndex
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libspdm_hip.so")
+LIB_PATH = os.environ.get("SPDM_LIB") or os.path.join(HERE, "libspdm_hip.so")     # (SPDM_LIB: A/B builds during kernel tuning)
 
 SPDM_DDPM, SPDM_DDIM = 0, 1
 SPDM_FLAG_DEBUG_KEEP = 1

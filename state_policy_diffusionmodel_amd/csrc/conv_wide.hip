@@ -47,6 +47,11 @@ constexpr float ACT_SCALE = 16.0f;            // same scales as conv_gemm.hip (2
 constexpr float DESCALE = 1.0f / 2048.0f;
 constexpr int CK = 32;
 constexpr int LDK = 36;
+#ifndef WIDE_NH
+#define WIDE_NH 2          // parts the output tile leaves in (epilogue LDS = M_T / WIDE_NH rows).  4 -> 40 KB per workgroup, i.e.
+                           // FOUR workgroups per CU instead of two: measured 0.06 ms per step SLOWER (9.72 / 9.53 vs 9.66 / 9.47 ms,
+                           // same box, alternating) -- the matrix pipe is clock-limited, more residents only add contention
+#endif
 
 __device__ __forceinline__ f32x2 split2(float a, float b) {
     const float xa = a * ACT_SCALE, xb = b * ACT_SCALE;
@@ -484,7 +489,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     // ---- epilogue: GroupNorm partial sums (fp32 per 4-row unit -> fp64 per sample, fixed order), then the
     //      tile through LDS in two halves so that every lane stores 16 bytes ----
     // accumulator layout: lane (l16, kg), register j of tile (rt, ct) = row 16 rt + 4 kg + j, column 16 ct + l16
-    constexpr int HROWS = M_T / 2;                       // rows per half (RW / 2 of each wave)
+    constexpr int NH = W2 ? 2 : WIDE_NH;                 // the tile leaves in NH parts (RW / NH rows of each wave per part)
+    constexpr int HROWS = M_T / NH;
     float* otile = smem;                                 // [HROWS][N_T]
     float* srow = smem + HROWS * N_T;                    // [M_T / 4][WN][2]
 #pragma unroll
@@ -510,11 +516,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
     }
 
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         if (h) __syncthreads();
 #pragma unroll
-        for (int rq = 0; rq < RT / 2; ++rq) {
-            const int rt = (RT / 2) * h + rq;
+        for (int rq = 0; rq < RT / NH; ++rq) {
+            const int rt = (RT / NH) * h + rq;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int col_l = wn * NT * 32 + ct * 16 + l16;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
                 for (int j = 0; j < 4; ++j) {
                     // row inside the wave's half (64 rows): W2 (rt>>1 - 2h) 32 + 2 (4 kg + j) + parity, else rq 16 + 4 kg + j
                     const int rw = W2 ? ((rt >> 1) - 2 * h) * 32 + 2 * (4 * kg + j) + (rt & 1) : rq * 16 + 4 * kg + j;
-                    otile[(wm * (RW / 2) + rw) * N_T + col_l] = acc[rt][ct][j];
+                    otile[(wm * (RW / NH) + rw) * N_T + col_l] = acc[rt][ct][j];
                 }
             }
         }
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, 
 #pragma unroll 4
         for (int p = 0; p < HROWS / RPP; ++p) {
             const int lr = p * RPP + r0;
-            const int row = m0 + (lr / (RW / 2)) * RW + h * (RW / 2) + lr % (RW / 2);
+            const int row = m0 + (lr / (RW / NH)) * RW + h * (RW / NH) + lr % (RW / NH);
             if (row < M) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(otile + lr * N_T + c4o * 4);
                 *reinterpret_cast<f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4o * 4) = v;
@@ -603,7 +609,7 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     size_t lds = (size_t)((QA + 2) * LDK + 2 * NS) * sizeof(float);
-    lds = std::max(lds, (size_t)((M_T / 2) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
+    lds = std::max(lds, (size_t)((M_T / (W2 ? 2 : WIDE_NH)) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
