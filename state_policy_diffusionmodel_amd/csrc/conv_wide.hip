@@ -74,7 +74,13 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
 }
 
 template <int NT, int PRO, bool W2, int RT, int WN>
-__global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS) {
+// launch bound (256, 2): a 256-register budget.  The 8 x 2 variants with a prologue then carry 88-128 bytes of scratch per lane
+// (stats finalisation state parked across the main loop); with (256, 1) the compiler allocates 203-250 registers and no scratch,
+// but schedules the loop worse: measured 10.5 vs 9.6-9.9 ms per step (same box, alternating).  Keep 2.
+#ifndef WIDE_MINB
+#define WIDE_MINB 2
+#endif
+__global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS) {
     constexpr int WM = 4 / WN;                          // 4 waves: 2 x 2, or 4 x 1 for 64-wide outputs (each wave 64 rows x 64 columns)
     constexpr int CT = 2 * NT;                          // RT 16-row x CT 16-column tiles per wave (RT = 8: 128-row strip;
                                                         // RT = 4: 64 rows -- 128-row workgroup tiles for small / coarse layers)
