@@ -207,10 +207,22 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     f32x4 areg[APASS];
     f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};
 
+    // The per-pass row addresses are loop-invariant; hoisted out of the main loop they cost ~24 registers, which the
+    // 128-row-per-wave variants with a prologue do not have: they came back as 16 scratch reloads per tap (88-128 bytes of
+    // scratch per lane).  There an opaque copy of the thread's row makes the compiler recompute the addresses (a few
+    // integer ops per pass) at each hand-over instead: no scratch, -3 % on up3.dc1.second / up1.dc1.second.  Everywhere
+    // else the hoisted form measured 2-5 % FASTER (tools/bench_gemm.py, alternating builds), so it stays.
+    int srow_o = srow_t;
+#ifdef WIDE_NO_OPAQUE
+#define WIDE_OPAQUE_ROW
+#else
+#define WIDE_OPAQUE_ROW if constexpr (PRO != PRO_NONE && RT == 8) asm volatile("" : "+v"(srow_o));
+#endif
 #define WIDE_LOAD_A(chunk_)                                                                          \
     {                                                                                                \
+        WIDE_OPAQUE_ROW                                                                              \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                      \
-            const int mc_ = min(max(m0 - halo + p_ * RP + srow_t, 0), M - 1);                        \
+            const int mc_ = min(max(m0 - halo + p_ * RP + srow_o, 0), M - 1);                        \
             areg[p_] = *reinterpret_cast<const f32x4*>(abase + (size_t)mc_ * a.src_ld + (chunk_) * CK); \
         }                                                                                            \
         if (pro) {                                                                                   \
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
             if (!((avalid >> p_) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                              \
             const f32x2 p0_ = split2(v_.x, v_.y), p1_ = split2(v_.z, v_.w);                          \
             {   /* rows past the slab go to a dump row: no branch (see the header) */                 \
-                float* row_ = Abuf + min(p_ * RP + srow_t, QA + 1) * LDK;                            \
+                float* row_ = Abuf + min(p_ * RP + srow_o, QA + 1) * LDK;                            \
                 *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{p0_.x, p1_.x};       /* hi */       \
                 *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{p0_.y, p1_.y};  /* lo */       \
             }                                                                                        \
