@@ -47,6 +47,9 @@ constexpr float ACT_SCALE = 16.0f;            // same scales as conv_gemm.hip (2
 constexpr float DESCALE = 1.0f / 2048.0f;
 constexpr int CK = 32;
 constexpr int LDK = 36;
+#ifndef WIDE_STAGE_GROUP
+#define WIDE_STAGE_GROUP 1
+#endif
 #ifndef WIDE_NH
 #define WIDE_NH 2          // parts the output tile leaves in (epilogue LDS = M_T / WIDE_NH rows).  4 -> 40 KB per workgroup, i.e.
                            // FOUR workgroups per CU instead of two: measured 0.06 ms per step SLOWER (9.72 / 9.53 vs 9.66 / 9.47 ms,
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
                 *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{p0_.x, p1_.x};       /* hi */       \
                 *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{p0_.y, p1_.y};  /* lo */       \
             }                                                                                        \
-            if (pro) __builtin_amdgcn_sched_barrier(0);        /* one pass at a time: register pressure */ \
+            if (pro && (p_ % WIDE_STAGE_GROUP) == WIDE_STAGE_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   /* WIDE_STAGE_GROUP passes at a time: register pressure */ \
         }                                                                                            \
     }
     // B ring slot <- the two 16-column tiles (cp_ 2, cp_ 2 + 1) of tap tap_ in chunk chunk_
