@@ -747,6 +747,13 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
             if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3>(a, g, s);
             return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3>(a, g, s);
         }
+        // few workgroups (small batches): the K loop is paced by one weight fetch per iteration, so walk three taps per
+        // iteration (3 x the bytes in flight per round trip)
+        const long long wgs = (long long)((a.M + 127) / 128) * g.n_tiles;
+        if (wgs <= 512 && getenv("SPDM_NO_SMALL_TPI3") == nullptr) {
+            if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2, 3>(a, g, s);
+            return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 3>(a, g, s);
+        }
         if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2, 1>(a, g, s);
         return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 1>(a, g, s);
     }
