@@ -166,6 +166,21 @@ int  spdm_sample_result(spdm_handle* h, float* d_out, void* stream);
 int  spdm_debug_tensor(spdm_handle* h, const char* name, float* d_out, size_t cap_floats,
                        int32_t shape_out[4]);
 
+/* Range guard of the split-precision contractions.  The split-fp16 path represents |weight| < 511 and
+ * |activation| < 4094.  Weights: spdm_load_weights checks every tensor and keeps a layer whose
+ * tensor exceeds the bound on the exact fp32 kernels (spdm_demoted_tensors counts them; results stay within the
+ * parity tolerance, that layer runs slower).  Activations: the step-update kernel raises a device flag when an
+ * updated iterate (or, for spdm_unet_forward, an eps value) is not finite; spdm_nonfinite synchronises `stream`
+ * and returns it (reset by spdm_sample_begin / spdm_unet_forward).  The reference's fp32 torch path
+ * (models/diffusion_ddpm.py:261-263) has neither limit; a caller that hits the flag re-creates the handle with
+ * SPDM_FLAG_EXACT_FP32. */
+int32_t spdm_demoted_tensors(const spdm_handle* h);
+int  spdm_nonfinite(spdm_handle* h, int32_t* flag_out, void* stream);
+
+/* Flip one kernel-selection switch ("SPDM_NO_GRAPH", "SPDM_NO_WIDE", ... -- the names the environment is read for,
+ * ONCE, at spdm_create) on a live handle.  Test / tuning hook: the product path never calls it. */
+int  spdm_set_switch(spdm_handle* h, const char* name, int32_t on);
+
 /* 1 if the handle's contractions run on the split-fp16 MFMA path, 0 on the exact fp32 MFMA path. */
 int32_t spdm_uses_split_precision(const spdm_handle* h);
 

@@ -7,10 +7,11 @@ CPU restatement, in torch-CPU fp32 functional ops, of the encoder half of the re
     Conv2d(3,16,2,stride=2,padding=1) ReLU  Conv2d(16,32,2,stride=2) ReLU  Conv2d(32,64,2,stride=2) ReLU
     Flatten  Linear(64*12*12, 128)
 
-PARITY UNPINNED: the reference file imports ``pytorch_lightning`` and ``torchvision`` at module level (neither is
-installed here), ships no checkpoint of this network and has no test or fixture for it, so this restatement is written
-from the file's text and checked only against ``torch.nn`` modules constructed with the same arguments
-(``tests/test_encoder.py``).  Only ``tests/`` and ``__graft_entry__.smoke()`` may import this file.
+PINNED: ``tools/make_golden.py::encoder_case`` imports the reference ``Autoencoder`` class itself (stubbing the two
+module-level imports the encoder never touches, ``pytorch_lightning`` and ``torchvision``), loads the tensors of
+``make_encoder_state_dict`` into its ``.encoder`` with ``strict=True`` and commits its output on seeded frames
+(``tests/golden/encoder_n5.npz``); ``tests/test_encoder.py`` checks this restatement -- and the HIP encoder -- against
+that fixture.  Only ``tests/`` and ``__graft_entry__.smoke()`` may import this file.
 """
 from __future__ import annotations
 

@@ -43,6 +43,9 @@ SYMBOLS = {
     "spdm_sample_result": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "spdm_debug_tensor": (c_int32, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_int32 * 4)]),
     "spdm_uses_split_precision": (c_int32, [c_void_p]),
+    "spdm_demoted_tensors": (c_int32, [c_void_p]),
+    "spdm_nonfinite": (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
+    "spdm_set_switch": (c_int32, [c_void_p, c_char_p, c_int32]),
     "spdm_device_bytes": (c_size_t, [c_void_p]),
     "spdm_profile_enable": (c_int32, [c_void_p, c_int32]),
     "spdm_profile_read": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),

@@ -340,10 +340,10 @@ static hipError_t launch_attention_mfma(const float* qkv, float* out, int B, int
     return hipGetLastError();
 }
 
-hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s) {
+hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int C, int heads, unsigned sw, hipStream_t s) {
     if (B <= 0 || L <= 0 || heads <= 0 || C % heads != 0 || C % 4 != 0) return hipErrorInvalidValue;
     const int d = C / heads;
-    if (L >= 32 && getenv("SPDM_ATTN_VALU") == nullptr) {
+    if (L >= 32 && !(sw & SW_ATTN_VALU)) {
         switch (d) {
             case 16: return launch_attention_mfma<16>(qkv, out, B, L, C, heads, s);
             case 32: return launch_attention_mfma<32>(qkv, out, B, L, C, heads, s);

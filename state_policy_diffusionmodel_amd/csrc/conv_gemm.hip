@@ -660,7 +660,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 // Tile choice is occupancy-aware: the 8-wave 256-row configuration only when it still yields enough
 // workgroups to cover the 256 CUs; otherwise 128-row tiles, and 64-wide instead of 128-wide tiles when even
 // those would leave CUs idle (small batches / coarse levels).
-GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
+GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split, unsigned sw) {
     GemmGeom g;
     const int nt128 = (N % 128 == 0) ? N / 128 : 0;
     const int nt_pref = nt128 ? nt128 : N / 64;
@@ -668,14 +668,14 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
     if (big && (long long)((M + 255) / 256) * nt_pref < 192) big = false;
     // 3-tap convs (W == 1 level): 128-row tiles (conv_wide's 4 x (64 x 64) variant, two workgroups per CU) until the
     // 256-row tiling would give every CU two workgroups
-    if (big && taps == 3 && HW % 4 == 0 && (long long)((M + 255) / 256) * nt_pref < 512 && getenv("SPDM_T3_BIG") == nullptr) big = false;
+    if (big && taps == 3 && HW % 4 == 0 && (long long)((M + 255) / 256) * nt_pref < 512 && !(sw & SW_T3_BIG)) big = false;
     g.m_tile = big ? 256 : 128;
     g.n_tile = nt128 ? 128 : 64;
     if (!big && nt128 && (long long)((M + 127) / 128) * nt128 < 192) g.n_tile = 64;
     // 64-wide outputs: 512-row tiles keep 72 MFMAs per wave between barriers (8 waves x 64x64)
     // (superseded for HW % 4 == 0 by conv_wide.hip's 256 x 64 configuration, two workgroups per CU)
     if (big && g.n_tile == 64 && taps == 9 && (long long)((M + 511) / 512) * (N / 64) >= 192 &&
-        getenv("SPDM_NO_T512") == nullptr && ((HW & 3) != 0 || getenv("SPDM_T512") != nullptr))
+        !(sw & SW_NO_T512) && ((HW & 3) != 0 || (sw & SW_T512)))
         g.m_tile = 512;
     g.n_tiles = N / g.n_tile;
     g.slots = stats_slots(HW, g.m_tile, g.n_tiles);
@@ -684,10 +684,10 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split) {
 
 // 2 x MACs the launch actually evaluates (the W = 2 zero-tap skipping runs 6 of the 9 taps)
 static bool uses_w2(const GemmArgs& a, const GemmGeom& g) {
-    return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && getenv("SPDM_NO_W2") == nullptr;
+    return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && !(a.sw & SW_NO_W2);
 }
 double gemm_flops(const GemmArgs& a) {
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split);
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split, a.sw);
     const double taps = uses_w2(a, g) ? 6.0 : (double)a.taps;
     return 2.0 * (double)a.M * (double)a.N * (double)a.K * taps;
 }
@@ -731,7 +731,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.epi == EPI_STATS && a.epi_stats == nullptr) return hipErrorInvalidValue;
     if ((a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID) && a.bias == nullptr) return hipErrorInvalidValue;
     if (a.epi == EPI_BIAS_RESID && a.resid == nullptr) return hipErrorInvalidValue;
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split);
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split, a.sw);
     if (a.split) {
         if (a.taps == 1) {
             if (g.n_tile == 128) return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 2, 1>(a, g, s);
@@ -750,7 +750,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         // few workgroups (small batches): the K loop is paced by one weight fetch per iteration, so walk three taps per
         // iteration (3 x the bytes in flight per round trip)
         const long long wgs = (long long)((a.M + 127) / 128) * g.n_tiles;
-        if (wgs <= 512 && getenv("SPDM_NO_SMALL_TPI3") == nullptr) {
+        if (wgs <= 512 && !(a.sw & SW_NO_SMALL_TPI3)) {
             if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2, 3>(a, g, s);
             return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 3>(a, g, s);
         }

@@ -641,7 +641,7 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
 
 }  // namespace
 
-static bool wide_w2(const GemmArgs& a) { return a.W == 2 && a.taps == 9 && getenv("SPDM_NO_W2") == nullptr; }
+static bool wide_w2(const GemmArgs& a) { return a.W == 2 && a.taps == 9 && !(a.sw & SW_NO_W2); }
 
 // Which layers run here: split-precision 3x3 convs (and the 3x1 convs of the W == 1 level) with GroupNorm-statistics
 // epilogue whose tiling (gemm_geometry) is 256 x {128, 64} -- or 128 x 128 (small batches, coarse levels), where the
@@ -649,11 +649,11 @@ static bool wide_w2(const GemmArgs& a) { return a.W == 2 && a.taps == 9 && geten
 bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
     const bool common = a.split && a.wgt_frag != nullptr && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 && a.M % a.HW == 0 &&
                         a.epi == EPI_STATS && a.row_stats == nullptr && a.K % CK == 0 &&
-                        (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && getenv("SPDM_NO_WIDE") == nullptr;
+                        (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && !(a.sw & SW_NO_WIDE);
     if (!common) return false;
     if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > 128) return false;       // 7-bit packed sample index per staging pass
     if (g.m_tile == 128)            // small tiles: the tap-pair loop only (128-wide, taps walked in pairs)
-        return g.n_tile == 128 && (a.taps == 9 || (a.taps == 3 && a.W == 1)) && a.K % 64 == 0 && getenv("SPDM_NO_WIDE128") == nullptr;
+        return g.n_tile == 128 && (a.taps == 9 || (a.taps == 3 && a.W == 1)) && a.K % 64 == 0 && !(a.sw & SW_NO_WIDE128);
     if (g.m_tile != 256) return false;
     if (a.taps == 3) return false;       // 256-row tiles of the W == 1 level (one workgroup per CU at most): conv_gemm's 8-wave
                                          // configuration measured faster (92 vs 139 us on 512 -> 512 at B = 4096)
@@ -683,7 +683,7 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
     }
     // 64-wide outputs: four waves along M, each 64 rows x all 64 columns (an A fragment feeds 12 MFMAs, as on 128-wide
     // tiles), tap-pair loop; K % 64 != 0 keeps the 2 x 2 arrangement with 128 x 32 waves
-    if (a.K % 64 == 0 && getenv("SPDM_WIDE_N64_2X2") == nullptr) {
+    if (a.K % 64 == 0 && !(a.sw & SW_WIDE_N64_2X2)) {
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 1>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 1>(a, g, s);
         return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 1>(a, g, s);

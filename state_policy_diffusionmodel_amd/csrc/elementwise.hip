@@ -448,7 +448,11 @@ __global__ __launch_bounds__(256) void out_step_kernel(const StepArgs a) {
     for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
     const float eps = dot + a.bias;
     if (!live || l16 != 0) return;
-    if (a.eps_out != nullptr) { a.eps_out[e] = eps; return; }
+    if (a.eps_out != nullptr) {
+        a.eps_out[e] = eps;
+        if (!(fabsf(eps) <= 3.0e38f)) *a.flag_dev = 1;
+        return;
+    }
 
     const int i = *a.step_dev;
     const float* c = a.coef + (size_t)i * 6;
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(256) void out_step_kernel(const StepArgs a) {
         if (c[5] != 0.f) {
             const float z = (a.noise != nullptr)
                                 ? a.noise[((size_t)i * a.B + b) * HD + he]
-                                : philox_normal(a.seed, (unsigned)(a.sample_offset + (unsigned long long)b),
+                                : philox_normal(a.rng_dev[0], (unsigned)(a.rng_dev[1] + (unsigned long long)b),
                                                 (unsigned)i, (unsigned)he);
             prev = __fadd_rn(prev, __fmul_rn(c[5], z));
         }
@@ -470,6 +474,8 @@ __global__ __launch_bounds__(256) void out_step_kernel(const StepArgs a) {
     if (h0 < a.inp_h && a.inpaint != nullptr)
         prev = a.inpaint[(a.inpaint_per_sample ? (size_t)b * a.inp_h * a.D : 0) + (size_t)h0 * a.D + d];
     a.x[e] = prev;
+    // overflow guard of the split-precision contractions (|activation| < 4094): surfaced by spdm_sample_nonfinite
+    if (!(fabsf(prev) <= 3.0e38f)) *a.flag_dev = 1;
     if (a.history != nullptr) a.history[((size_t)(i + 1) * a.B + b) * HD + he] = prev;
 }
 

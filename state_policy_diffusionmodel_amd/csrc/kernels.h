@@ -49,6 +49,28 @@ __host__ __device__ inline int stats_slots(int HW, int m_tile, int n_tiles) {
     return ((HW + m_tile - 2) / m_tile + 1) * n_tiles;
 }
 
+// Kernel-selection switches.  Read from the environment ONCE (spdm_create / spdm_bench_gemm: switches_from_env) and
+// carried in the handle; every launch decision and the step-graph key derive from this one word, so a mid-session
+// change of the environment cannot change which kernels run.  spdm_set_switch flips one on a live handle (tests).
+enum : unsigned {
+    SW_NO_WIDE = 1u << 0, SW_NO_WIDE128 = 1u << 1, SW_NO_W2 = 1u << 2, SW_NO_T512 = 1u << 3, SW_T512 = 1u << 4,
+    SW_T3_BIG = 1u << 5, SW_NO_SMALL_TPI3 = 1u << 6, SW_WIDE_N64_2X2 = 1u << 7, SW_NO_SA_FUSED = 1u << 8,
+    SW_NO_SA_TAIL = 1u << 9, SW_ATTN_VALU = 1u << 10, SW_SA_NO_WLDS = 1u << 11, SW_NO_FILM_FOLD = 1u << 12,
+    SW_NO_GRAPH = 1u << 13, SW_NO_SPLITK = 1u << 14, SW_ARENA_TRACE = 1u << 15,
+};
+struct SwitchName { const char* env; unsigned bit; };
+inline const SwitchName* switch_table(int* n) {
+    static const SwitchName t[] = {
+        {"SPDM_NO_WIDE", SW_NO_WIDE}, {"SPDM_NO_WIDE128", SW_NO_WIDE128}, {"SPDM_NO_W2", SW_NO_W2}, {"SPDM_NO_T512", SW_NO_T512},
+        {"SPDM_T512", SW_T512}, {"SPDM_T3_BIG", SW_T3_BIG}, {"SPDM_NO_SMALL_TPI3", SW_NO_SMALL_TPI3},
+        {"SPDM_WIDE_N64_2X2", SW_WIDE_N64_2X2}, {"SPDM_NO_SA_FUSED", SW_NO_SA_FUSED}, {"SPDM_NO_SA_TAIL", SW_NO_SA_TAIL},
+        {"SPDM_ATTN_VALU", SW_ATTN_VALU}, {"SPDM_SA_NO_WLDS", SW_SA_NO_WLDS}, {"SPDM_NO_FILM_FOLD", SW_NO_FILM_FOLD},
+        {"SPDM_NO_GRAPH", SW_NO_GRAPH}, {"SPDM_NO_SPLITK", SW_NO_SPLITK}, {"SPDM_ARENA_TRACE", SW_ARENA_TRACE}};
+    *n = (int)(sizeof(t) / sizeof(t[0]));
+    return t;
+}
+unsigned switches_from_env();          // spdm_api.hip
+
 enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_GELU = 2 };
 enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RESID = 3, EPI_PLAIN = 4 };
 
@@ -64,6 +86,7 @@ struct GemmArgs {
     int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
     int epi;  double* epi_stats;   const float* bias;  const float* resid;  int resid_ld;
     double* row_stats;                 // optional: per-row {sum, sum^2} of the STORED values, [row][n_tiles][2] (LayerNorm of the consumer)
+    unsigned sw;                       // kernel-selection switches (SW_*) of the owning handle
     int debug;                         // ablation knobs for spdm_bench_gemm only (0 in the product path)
     unsigned long long* stamps;        // DBG_STAMP: [2][128] s_memtime stamps of one workgroup (diagnostic builds of the bench)
 };
@@ -71,7 +94,7 @@ enum { DBG_NO_MFMA = 1, DBG_NO_WLOAD = 2, DBG_NO_GELU = 4, DBG_NO_STORE = 8, DBG
 
 // geometry of the stats the GEMM writes (EPI_STATS)
 struct GemmGeom { int m_tile, n_tile, n_tiles, slots; };
-GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split);
+GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split, unsigned sw);
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 // conv_wide.hip: the 4-wave / 128x64-per-wave configuration of the 3x3 implicit GEMM (256 x 128 tiles, two
@@ -143,7 +166,8 @@ struct StepArgs {
     const int* step_dev;          // device scalar: loop iteration
     int kind;
     const float* noise;           // (n_steps, B, H0, D) or null
-    unsigned long long seed, sample_offset;
+    const unsigned long long* rng_dev;   // device {seed, first global trajectory index} of the Philox noise stream
+    int* flag_dev;                // device word, set to 1 when an updated iterate (or eps) is not finite
     const float* inpaint; int inp_h; int inpaint_per_sample;
     float* history;               // (n_steps+1, B, H0, D) or null
     int B, H0, D, Hp, Wp, lh, lw;
@@ -155,7 +179,7 @@ hipError_t launch_set_step(int* step_dev, int* t_dev, const int* timesteps_dev, 
 // ---- attention core (attention.hip): softmax(q k^T / sqrt d) v per (sample, head) -----------
 hipError_t launch_attention(const float* qkv /*[B*L][3C]*/, float* out /*[B*L][C]*/, int B, int L, int C,
                             int heads, hipStream_t s);        // VALU kernel (small L)
-hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s);  // MFMA kernel for L >= 32
+hipError_t launch_attention_auto(const float* qkv, float* out, int B, int L, int C, int heads, unsigned sw, hipStream_t s);  // MFMA kernel for L >= 32
 
 // ---- fused SelfAttention block for the C = 64 levels (sa_fused.hip) -------------------------------------
 bool sa_fused_supported(int L, int C);
@@ -164,10 +188,10 @@ bool sa_fused_supported(int L, int C);
 // ab (optional): the block input is ab-affine of x per sample (film_coef_kernel), applied on load
 hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
-                             const float* bo, const float* b1, const float* b2, const float* ab, hipStream_t s);
+                             const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s);
 
 // ---- row-wise tail of a C = 128 SelfAttention block (sa_tail.hip): out_proj + x -> LayerNorm -> ff1 -> GELU -> ff2 + av ----
-bool sa_tail_supported(int C);
+bool sa_tail_supported(int C, unsigned sw);
 hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                              const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
                              const float* ln_b, const float* ab, int L, hipStream_t s);

@@ -497,7 +497,7 @@ bool sa_fused_supported(int L, int C) { return C == SA_C && L >= 1 && L <= 512; 
 
 hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
-                             const float* bo, const float* b1, const float* b2, const float* ab, hipStream_t s) {
+                             const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s) {
     if (!sa_fused_supported(L, SA_C) || B <= 0) return hipErrorInvalidValue;
     SaFusedArgs a{};
     a.x = x; a.out = out; a.L = L;
@@ -511,7 +511,7 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     if (pair && ab != nullptr) return hipErrorInvalidValue;                       // (the plan keeps film_apply there)
     const int nwave = pair ? 8 : (L + 31) / 32;
     const int Lp = pair ? 512 : nwave * 32;
-    const bool wlds = !pair && (nwave >= 4) && getenv("SPDM_SA_NO_WLDS") == nullptr;      // long sequences: weights staged in LDS
+    const bool wlds = !pair && (nwave >= 4) && !(sw & SW_SA_NO_WLDS);      // long sequences: weights staged in LDS
     const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16) +
                        2 * SA_C * sizeof(float);                                               // + the FiLM-coefficient row
     if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
 
 }  // namespace
 
-bool sa_tail_supported(int C) { return C == T_C && getenv("SPDM_NO_SA_TAIL") == nullptr; }
+bool sa_tail_supported(int C, unsigned sw) { return C == T_C && !(sw & SW_NO_SA_TAIL); }
 
 hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                              const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,

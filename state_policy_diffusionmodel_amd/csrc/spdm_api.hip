@@ -139,6 +139,8 @@ struct spdm_handle {
     float outc_b = 0.f;
     bool weights_loaded = false, temb_ready = false;
     bool split = true;                    // split-fp16 MFMA path (default); SPDM_PREC=f32 selects the exact fp32 MFMA path
+    unsigned sw = 0;                      // kernel-selection switches (SW_*, kernels.h): environment read once at create
+    int demoted = 0;                      // tensors outside the split format's range, kept on the exact fp32 kernels
     std::vector<float> time_table;        // host (T, time_dim)
     float* d_time_silu = nullptr;         // device SiLU(pos_encoding) (T, time_dim)
     // schedule
@@ -148,7 +150,8 @@ struct spdm_handle {
     float* d_coef = nullptr;
     // persistent per-call state (sized for max_batch)
     int* d_t = nullptr;                   // [max_batch] timestep(s) of the current evaluation
-    int* d_step = nullptr;                // loop iteration
+    int* d_step = nullptr;                // [0] loop iteration, [2] non-finite flag (set by out_step_kernel)
+    unsigned long long* d_rng = nullptr;  // {seed, first global trajectory index} of the device noise stream
     float* d_condm = nullptr;             // Mish(cond), K padded
     float* d_film[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* d_x = nullptr;                 // current iterate (B,H0,D)
@@ -170,12 +173,13 @@ struct spdm_handle {
     struct StepGraphKey {
         int B = 0, inp_h = 0, per_sample = 0, have_film = 0, sched_kind = 0, n_steps = 0;
         const void *inpaint = nullptr, *noise = nullptr, *history = nullptr;
-        unsigned long long seed = 0, offset = 0;
-        unsigned env = 0;                 // which kernel-selection switches (SPDM_NO_WIDE, ...) were set when the step was captured
+        unsigned env = 0;                 // the handle's kernel-selection switches when the step was captured
+        // (seed and trajectory offset are NOT part of the key: out_step_kernel reads them from d_rng, so a fresh seed per
+        //  sample() call replays the same graph)
         bool operator==(const StepGraphKey& o) const {
             return env == o.env && B == o.B && inp_h == o.inp_h && per_sample == o.per_sample && have_film == o.have_film &&
                    sched_kind == o.sched_kind && n_steps == o.n_steps && inpaint == o.inpaint && noise == o.noise &&
-                   history == o.history && seed == o.seed && offset == o.offset;
+                   history == o.history;
         }
     } graph_key;
     hipGraph_t step_graph = nullptr;
@@ -260,6 +264,15 @@ static void default_time_table(std::vector<float>& tab, int T, int dim) {
 }
 
 // -------------------------------------------------------------------------------------------------
+unsigned spdm::switches_from_env() {
+    int n = 0;
+    const SwitchName* t = switch_table(&n);
+    unsigned sw = 0;
+    for (int i = 0; i < n; ++i)
+        if (getenv(t[i].env) != nullptr) sw |= t[i].bit;
+    return sw;
+}
+
 extern "C" int spdm_abi_version(void) { return SPDM_ABI_VERSION; }
 extern "C" const char* spdm_last_error(void) { return g_err; }
 
@@ -309,6 +322,7 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
     HIP_TRY(hipSetDevice(cfg->device));
     spdm_handle* h = new spdm_handle();
     h->cfg = *cfg;
+    h->sw = switches_from_env();          // the ONLY place the product path reads SPDM_* switches
     if (const char* pe = getenv("SPDM_PREC")) h->split = !(strcmp(pe, "f32") == 0 || strcmp(pe, "fp32") == 0);
     if (cfg->flags & SPDM_FLAG_EXACT_FP32) h->split = false;
     // pad_to(x, 8): models/Unet_FiLmLayer.py:15-28
@@ -324,6 +338,8 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
     do {
         if ((rc = dev_alloc(h, (void**)&h->d_t, sizeof(int) * mb))) break;
         if ((rc = dev_alloc(h, (void**)&h->d_step, sizeof(int) * 4))) break;
+        if ((rc = dev_alloc(h, (void**)&h->d_rng, sizeof(unsigned long long) * 2))) break;
+        if (hipMemset(h->d_step, 0, sizeof(int) * 4) != hipSuccess) { rc = fail(SPDM_ERR_HIP, "memset failed"); break; }
         if ((rc = dev_alloc(h, (void**)&h->d_condm, sizeof(float) * (size_t)mb * h->film_kp))) break;
         static const int film_c[6] = {128, 256, 256, 128, 64, 64};
         for (int i = 0; i < 6 && !rc; ++i) rc = dev_alloc(h, (void**)&h->d_film[i], sizeof(float) * (size_t)mb * 2 * film_c[i]);
@@ -340,7 +356,7 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
         hipError_t e = hipMalloc((void**)&h->arena.base, h->arena.cap);
         if (e != hipSuccess) { rc = fail(SPDM_ERR_NOMEM, "workspace of %zu bytes: %s", h->arena.cap, hipGetErrorString(e)); break; }
         h->owned.push_back(h->arena.base);
-        if (getenv("SPDM_ARENA_TRACE")) fprintf(stderr, "[spdm] arena %p, %zu MiB\n", (void*)h->arena.base, h->arena.cap >> 20);
+        if (h->sw & SW_ARENA_TRACE) fprintf(stderr, "[spdm] arena %p, %zu MiB\n", (void*)h->arena.base, h->arena.cap >> 20);
     } while (0);
     if (rc) { spdm_destroy(h); return rc; }
     default_time_table(h->time_table, cfg->num_train_timesteps, cfg->time_dim);
@@ -388,6 +404,13 @@ struct Loader {
     }
     // fp32 [rows][K] -> per 32-k chunk [32 x fp16 hi | 32 x fp16 lo] of x' = 128 x (conv_gemm.hip, PREC_SPLIT):
     // hi = fp16(x'), lo = fp16(x' - hi); same byte size as the fp32 array
+    // The split format scales weights by 2^7 before the fp16 cast: |w| >= 511.75 would become inf.  Such a tensor gets no
+    // split copy and its layer runs on the exact fp32 kernel instead (same results, 5x slower for that layer).
+    static bool split_range_ok(const std::vector<float>& v) {
+        float mx = 0.f;
+        for (float x : v) { const float ax = std::fabs(x); if (!(ax <= mx)) mx = ax; }    // NaN-propagating max
+        return mx < 511.0f;
+    }
     static std::vector<float> split_format(const std::vector<float>& v) {
         std::vector<float> out(v.size());
         for (size_t base = 0; base < v.size(); base += 32) {
@@ -403,6 +426,7 @@ struct Loader {
     }
     float* upload_split(const std::vector<float>& v, size_t K) {
         if (K % 32 != 0) { err = fail(SPDM_ERR_INVALID, "split weights need K %% 32 == 0"); return nullptr; }
+        if (!split_range_ok(v)) { if (h) ++h->demoted; return nullptr; }
         return upload(split_format(v));
     }
     float* upload(const std::vector<float>& v) {
@@ -429,7 +453,7 @@ struct Loader {
         }
         c.w = upload(v);
         c.ws = (cin % 32 == 0) ? upload_split(v, cin) : nullptr;
-        if (cin % 32 == 0 && cout % 64 == 0) c.wf = upload(frag_order_weights(split_format(v), taps, cout, cin));
+        if (c.ws && cout % 64 == 0) c.wf = upload(frag_order_weights(split_format(v), taps, cout, cin));
         c.taps = taps; c.cin = cin; c.cout = cout;
         return c;
     }
@@ -475,6 +499,7 @@ struct Loader {
         static const int perm16[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
         const float* w = find(wname, {out, 64});
         if (!w) return;
+        if (!split_range_ok(std::vector<float>(w, w + (size_t)out * 64))) { ++h->demoted; return; }   // block falls back to the GEMM chain
         std::vector<_Float16> hi((size_t)out * 64), lo((size_t)out * 64);
         for (int o = 0; o < out; ++o)
             for (int g = 0; g < 4; ++g)
@@ -511,6 +536,7 @@ struct Loader {
     float* linear_frag(const std::string& wname, int out, int in) {
         const float* w = find(wname, {out, in});
         if (!w) return nullptr;
+        if (!split_range_ok(std::vector<float>(w, w + (size_t)out * in))) { ++h->demoted; return nullptr; }
         return upload(frag_order_weights(split_format(std::vector<float>(w, w + (size_t)out * in)), 1, out, in));
     }
     AttnW attn(const std::string& p, int C) {
@@ -527,7 +553,10 @@ struct Loader {
             perm_split(p + ".attention.out_proj.weight", 64, &a.fw[2], &a.fw[3]);
             perm_split(p + ".ff_self.1.weight", 64, &a.fw[4], &a.fw[5]);
             perm_split(p + ".ff_self.3.weight", 64, &a.fw[6], &a.fw[7]);
+            for (int k = 0; k < 8; ++k)
+                if (!a.fw[k]) { a.fw[0] = nullptr; break; }        // the fused kernel needs all four matrices
         }
+        if (C == 128 && !(a.tail_wf[0] && a.tail_wf[1] && a.tail_wf[2])) a.tail_wf[0] = nullptr;
         a.in_proj = linear(p + ".attention.in_proj_weight", p + ".attention.in_proj_bias", 3 * C, C, C);
         a.out_proj = linear(p + ".attention.out_proj.weight", p + ".attention.out_proj.bias", C, C, C);
         a.ln_g = vec(p + ".ln.weight", C);
@@ -596,7 +625,41 @@ extern "C" int spdm_load_weights(spdm_handle* h, const float* blob, size_t n, co
     SPDM_TRY(dev_alloc(h, (void**)&h->d_time_silu, sizeof(float) * (size_t)h->cfg.num_train_timesteps * h->cfg.time_dim));
     h->weights_loaded = true;
     h->temb_ready = false;
+    if (h->demoted > 0) {
+        // Some layers left the kernels the workspace was sized for (create() planned by shape only): plan again with the
+        // weights known and grow the slab if this plan needs more.
+        h->arena.dry = true;
+        h->arena.peak = 0;
+        h->arena.reset();
+        Tensor feat;
+        const int rc = plan_forward(h, h->cfg.max_batch, true, nullptr, &feat);
+        h->arena.dry = false;
+        if (rc != SPDM_OK) return rc;
+        if (align_up(h->arena.peak, 4096) > h->arena.cap) {
+            char* nb = nullptr;
+            const size_t cap = align_up(h->arena.peak, 4096);
+            hipError_t e = hipMalloc((void**)&nb, cap);
+            if (e != hipSuccess) return fail(SPDM_ERR_NOMEM, "workspace of %zu bytes: %s", cap, hipGetErrorString(e));
+            h->owned.push_back(nb);        // (the smaller slab stays owned until destroy)
+            h->arena.base = nb;
+            h->arena.cap = cap;
+        }
+    }
     return SPDM_OK;
+}
+
+extern "C" int32_t spdm_demoted_tensors(const spdm_handle* h) { return h ? h->demoted : 0; }
+
+extern "C" int spdm_set_switch(spdm_handle* h, const char* name, int32_t on) {
+    if (!h || !name) return fail(SPDM_ERR_INVALID, "null argument");
+    int n = 0;
+    const SwitchName* t = switch_table(&n);
+    for (int i = 0; i < n; ++i)
+        if (strcmp(t[i].env, name) == 0) {
+            h->sw = on ? (h->sw | t[i].bit) : (h->sw & ~t[i].bit);
+            return SPDM_OK;
+        }
+    return fail(SPDM_ERR_INVALID, "unknown switch '%s'", name);
 }
 
 extern "C" int spdm_set_time_table(spdm_handle* h, const float* tab, int32_t T) {
@@ -661,7 +724,7 @@ struct Ctx {
             return t;
         }
         t.off = off; t.p = (float*)(h->arena.base + off); t.valid = true;
-        if (!dry && getenv("SPDM_ARENA_TRACE")) fprintf(stderr, "[spdm] level %d C %3d at %8.2f MiB (%.1f MiB)\n", level, C, off / 1048576.0, (double)B * HWl(level) * C * 4 / 1048576.0);
+        if (!dry && (h->sw & SW_ARENA_TRACE)) fprintf(stderr, "[spdm] level %d C %3d at %8.2f MiB (%.1f MiB)\n", level, C, off / 1048576.0, (double)B * HWl(level) * C * 4 / 1048576.0);
         return t;
     }
     Tensor ralloc(int rows, int C) {       // [rows][C] scratch (attention path)
@@ -713,13 +776,16 @@ struct Ctx {
     Value conv(const Value& in, const ConvW& w, int level, bool gelu, const float* gamma, const float* beta) {
         Value out;
         const int HW = HWl(level), M = B * HW;
-        const int split = (h->split && w.cin % 32 == 0) ? 1 : 0;   // decided by shape only: the dry run has no weights yet
-        const GemmGeom g = gemm_geometry(M, w.cout, HW, w.taps, split);
+        // by shape before the weights are known (the dry run at create); afterwards a tensor outside the split format's
+        // range has no split copy and stays on the exact fp32 kernel (Loader::conv)
+        const int split = (h->split && w.cin % 32 == 0 && (!h->weights_loaded || w.ws)) ? 1 : 0;
+        const GemmGeom g = gemm_geometry(M, w.cout, HW, w.taps, split, h->sw);
         out.t = talloc(w.cout, level);
         out.st = salloc(HW, w.cout, g.m_tile, g.n_tiles);
         out.gamma = gamma; out.beta = beta;
         if (err || dry) return out;
         GemmArgs a{};
+        a.sw = h->sw;
         a.split = split;
         a.src = in.t.p; a.src_ld = in.t.C; a.wgt = a.split ? w.ws : w.w; a.dst = out.t.p; a.dst_ld = w.cout;
         a.wgt_frag = a.split ? w.wf : nullptr;
@@ -785,6 +851,7 @@ struct Ctx {
                 double* row_stats_out = nullptr) {
         if (err || dry) return;
         GemmArgs a{};
+        a.sw = h->sw;
         a.split = (h->split && w.ws) ? 1 : 0;
         a.src = x; a.src_ld = ld; a.wgt = a.split ? w.ws : w.w; a.dst = y; a.dst_ld = w.out;
         a.M = rows; a.K = w.in; a.N = w.out; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
@@ -797,7 +864,7 @@ struct Ctx {
     // statistics xs, produced by film_apply), returns the block output.  Both LayerNorms run as the load
     // prologue of the GEMM that consumes them: self.ln -> in_proj, ff_self[0] -> ff_self[1].
     bool sa_fused(const AttnW& w, int level) const {
-        return h->split && sa_fused_supported(HWl(level), w.C) && getenv("SPDM_NO_SA_FUSED") == nullptr;
+        return h->split && sa_fused_supported(HWl(level), w.C) && !(h->sw & SW_NO_SA_FUSED) && (!h->weights_loaded || w.fw[0]);
     }
     // ab (optional): x is the RAW conv output and the block input is ab-affine of it (film_coef); consumed here.
     Tensor attention(Tensor& x, StatsBuf& xs, const AttnW& w, int level, Tensor* ab = nullptr) {
@@ -807,14 +874,14 @@ struct Ctx {
             Tensor out = talloc(C, level);
             if (!err && !dry)
                 check(launch_sa_fused64(x.p, out.p, B, L, w.ln_g, w.ln_b, w.ff_ln_g, w.ff_ln_b, w.fw, w.in_proj.b,
-                                        w.out_proj.b, w.ff1.b, w.ff2.b, abp, s), "fused attention block");
+                                        w.out_proj.b, w.ff1.b, w.ff2.b, abp, h->sw, s), "fused attention block");
             free(x);
             free(xs);
             if (ab) free(*ab);
             return out;
         }
         Tensor qkv = ralloc(rows, 3 * C);
-        if (h->split && sa_tail_supported(C) && (dry || w.qkv_wf)) {     // LayerNorm + in_proj in one 64-row kernel (sa_tail.hip)
+        if (h->split && sa_tail_supported(C, h->sw) && (!h->weights_loaded || w.qkv_wf)) {     // LayerNorm + in_proj in one 64-row kernel (sa_tail.hip)
             if (!err && !dry)
                 check(launch_sa_qkv128(x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s), "attention in_proj");
         } else {
@@ -822,9 +889,9 @@ struct Ctx {
         }
         free(xs);
         Tensor att = ralloc(rows, C);
-        if (!err && !dry) check(launch_attention_auto(qkv.p, att.p, B, L, C, 4, s), "attention core");
+        if (!err && !dry) check(launch_attention_auto(qkv.p, att.p, B, L, C, 4, h->sw, s), "attention core");
         free(qkv);
-        if (h->split && sa_tail_supported(C) && (dry || w.tail_wf[0])) {
+        if (h->split && sa_tail_supported(C, h->sw) && (!h->weights_loaded || w.tail_wf[0])) {
             // out_proj + residual + LayerNorm + ff_self + residual in one kernel (sa_tail.hip)
             Tensor out = talloc(C, level);
             if (!err && !dry)
@@ -836,7 +903,7 @@ struct Ctx {
             return out;
         }
         Tensor av = talloc(C, level);
-        const int nt_av = gemm_geometry(rows, C, 1, 1, (h->split && C % 32 == 0) ? 1 : 0).n_tiles;   // n-tiles of the out_proj GEMM
+        const int nt_av = gemm_geometry(rows, C, 1, 1, (h->split && w.out_proj.ws) ? 1 : 0, h->sw).n_tiles;   // n-tiles of the out_proj GEMM
         StatsBuf avs = row_stats_alloc(rows, C, nt_av);
         linear(att.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p, nullptr, nullptr, nullptr, avs.p);
         free(att);
@@ -853,9 +920,9 @@ struct Ctx {
     // May the FiLM tail feeding this attention block be folded into the block's loads?  Only the kernels that read the
     // block input themselves take the coefficients: sa_fused64 and the C = 128 pair sa_qkv128 / sa_tail128.
     bool film_foldable(const AttnW& w, int level) const {
-        if (!h->cfg.attention || h->arena.keep || !h->split || getenv("SPDM_NO_FILM_FOLD") != nullptr) return false;
+        if (!h->cfg.attention || h->arena.keep || !h->split || (h->sw & SW_NO_FILM_FOLD)) return false;
         if (sa_fused(w, level)) return HWl(level) <= 256;      // (the two-workgroup mode for longer sequences has no registers left)
-        return sa_tail_supported(w.C) && HWl(level) % 8 == 0 && (dry || (w.qkv_wf && w.tail_wf[0]));
+        return sa_tail_supported(w.C, h->sw) && HWl(level) % 8 == 0 && (!h->weights_loaded || (w.qkv_wf && w.tail_wf[0]));
     }
     // the FiLM tail as coefficients (film_coef_kernel): returns the RAW conv tensor of v (its statistics are released),
     // *ab receives [B][2 C]
@@ -999,6 +1066,7 @@ static int ensure_temb(spdm_handle* h, hipStream_t s) {
     ResampleW* blocks[6] = {&h->down[0], &h->down[1], &h->down[2], &h->up[0], &h->up[1], &h->up[2]};
     for (int i = 0; i < 6 && e == hipSuccess; ++i) {
         GemmArgs a{};
+        a.sw = h->sw;
         a.split = (h->split && blocks[i]->emb.ws) ? 1 : 0;
         a.src = h->d_time_silu; a.src_ld = dim; a.wgt = a.split ? blocks[i]->emb.ws : blocks[i]->emb.w; a.dst = blocks[i]->temb_table; a.dst_ld = blocks[i]->cout;
         a.M = T; a.K = dim; a.N = blocks[i]->cout; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
@@ -1021,6 +1089,7 @@ static int compute_film(spdm_handle* h, int B, const float* d_cond, hipStream_t 
     ResampleW* blocks[6] = {&h->down[0], &h->down[1], &h->down[2], &h->up[0], &h->up[1], &h->up[2]};
     for (int i = 0; i < 6 && e == hipSuccess; ++i) {
         GemmArgs a{};
+        a.sw = h->sw;
         a.split = (h->split && blocks[i]->film.ws) ? 1 : 0;
         a.src = h->d_condm; a.src_ld = h->film_kp; a.wgt = a.split ? blocks[i]->film.ws : blocks[i]->film.w; a.dst = h->d_film[i]; a.dst_ld = 2 * blocks[i]->cout;
         a.M = B; a.K = h->film_kp; a.N = 2 * blocks[i]->cout; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
@@ -1043,7 +1112,7 @@ static StepArgs step_args(spdm_handle* h, int B, const Tensor& feat) {
     StepArgs a{};
     a.feat = feat.p; a.w = h->outc_w; a.bias = h->outc_b; a.x = h->d_x; a.eps_out = nullptr;
     a.coef = h->d_coef; a.step_dev = h->d_step; a.kind = h->sched_kind;
-    a.noise = h->s_noise; a.seed = h->s_seed; a.sample_offset = h->s_offset;
+    a.noise = h->s_noise; a.rng_dev = h->d_rng; a.flag_dev = h->d_step + 2;
     a.inpaint = h->s_inpaint; a.inp_h = h->s_inp_h; a.inpaint_per_sample = h->s_inp_per_sample;
     a.history = h->s_history;
     a.B = B; a.H0 = h->cfg.horizon; a.D = h->cfg.state_dim; a.Hp = h->Hp; a.Wp = h->Wp; a.lh = h->lh; a.lw = h->lw;
@@ -1061,6 +1130,7 @@ extern "C" int spdm_unet_forward(spdm_handle* h, int32_t B, const float* d_x, co
     hipStream_t s = (hipStream_t)stream;
     SPDM_TRY(ensure_temb(h, s));
     HIP_TRY(hipMemcpyAsync(h->d_t, h_t, sizeof(int) * t_count, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->d_step + 2, 0, sizeof(int), s));
     HIP_TRY(hipMemcpyAsync(h->d_x, d_x, sizeof(float) * (size_t)B * h->cfg.horizon * h->cfg.state_dim, hipMemcpyDeviceToDevice, s));
     SPDM_TRY(compute_film(h, B, d_cond, s));
     h->taps.clear();
@@ -1099,6 +1169,11 @@ extern "C" int spdm_sample_begin(spdm_handle* h, int32_t B, const float* d_cond,
     h->s_history = d_history;
     h->s_seed = seed;
     h->s_offset = sample_offset;
+    {   // the noise stream's key lives on the device (read by out_step_kernel), so a new seed does not change the step's launches
+        const unsigned long long rng[2] = {seed, sample_offset};
+        HIP_TRY(hipMemcpyAsync(h->d_rng, rng, sizeof(rng), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(h->d_step + 2, 0, sizeof(int), s));
+    }
     h->session = true;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return SPDM_OK;
@@ -1152,7 +1227,7 @@ extern "C" int spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_
     HIP_TRY(hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     // Graph replay (default; SPDM_NO_GRAPH=1 disables): not while the per-launch profiler or the debug taps are on.
-    const bool graphs_on = getenv("SPDM_NO_GRAPH") == nullptr;
+    const bool graphs_on = !(h->sw & SW_NO_GRAPH);
     bool use_graph = graphs_on && !h->prof && !h->arena.keep && step_end - step_begin >= 3;
     if (use_graph && s == nullptr) {
         // the legacy NULL stream cannot be captured: run on a blocking stream of our own (implicitly ordered with
@@ -1167,14 +1242,8 @@ extern "C" int spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_
         spdm_handle::StepGraphKey key;
         key.B = h->sB; key.inp_h = h->s_inp_h; key.per_sample = h->s_inp_per_sample; key.have_film = h->have_film ? 1 : 0;
         key.sched_kind = h->sched_kind; key.n_steps = h->n_steps; key.inpaint = h->s_inpaint; key.noise = h->s_noise;
-        key.history = h->s_history; key.seed = h->s_seed; key.offset = h->s_offset;
-        {   // the captured launches depend on the kernel-selection switches too (tests flip them inside one process)
-            static const char* const sw[] = {"SPDM_ATTN_VALU", "SPDM_NO_FILM_FOLD", "SPDM_NO_SA_FUSED", "SPDM_NO_SA_TAIL", "SPDM_NO_T512", "SPDM_NO_W2",
-                                             "SPDM_NO_WIDE", "SPDM_NO_WIDE128", "SPDM_SA_NO_WLDS", "SPDM_T3_BIG", "SPDM_T512",
-                                             "SPDM_WIDE_N64_2X2"};
-            for (unsigned k = 0; k < sizeof(sw) / sizeof(sw[0]); ++k)
-                if (getenv(sw[k]) != nullptr) key.env |= 1u << k;
-        }
+        key.history = h->s_history;
+        key.env = h->sw;          // the captured launches depend on the kernel-selection switches (spdm_set_switch)
         if (!(h->step_exec && key == h->graph_key)) {
             if (build_step_graph(h, s)) h->graph_key = key;
             else use_graph = false;
@@ -1194,6 +1263,16 @@ extern "C" int spdm_sample_result(spdm_handle* h, float* d_out, void* stream) {
     HIP_TRY(hipMemcpyAsync(d_out, h->d_x, sizeof(float) * (size_t)h->sB * h->cfg.horizon * h->cfg.state_dim,
                            hipMemcpyDeviceToDevice, s));
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return SPDM_OK;
+}
+
+extern "C" int spdm_nonfinite(spdm_handle* h, int32_t* flag_out, void* stream) {
+    if (!h || !flag_out) return fail(SPDM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, h->d_step + 2, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *flag_out = v;
     return SPDM_OK;
 }
 
@@ -1270,7 +1349,8 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     if (!ms_out || iters < 1) return fail(SPDM_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(device));
     const int HW = H * W, M = B * HW;
-    const GemmGeom g = gemm_geometry(M, Cout, HW, taps, split);
+    const unsigned sw = switches_from_env();
+    const GemmGeom g = gemm_geometry(M, Cout, HW, taps, split, sw);
     float *src = nullptr, *wgt = nullptr, *wgt32 = nullptr, *dst = nullptr, *dst2 = nullptr, *gb = nullptr, *resid = nullptr, *wfrag = nullptr;
     double *st_in = nullptr, *st_out = nullptr, *st_out2 = nullptr;
     const size_t nsrc = (size_t)M * Cin, nw = (size_t)taps * Cout * Cin, ndst = (size_t)M * Cout;
@@ -1285,7 +1365,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     HIP_TRY(hipMalloc((void**)&st_in, (size_t)(row_ln ? M : B) * 2 * 8));
     HIP_TRY(hipMalloc((void**)&st_out, (size_t)B * g.slots * 2 * 8));
     HIP_TRY(hipMemset(st_out, 0, (size_t)B * g.slots * 2 * 8));
-    const GemmGeom g2 = gemm_geometry(M, Cout, HW, taps, 0);
+    const GemmGeom g2 = gemm_geometry(M, Cout, HW, taps, 0, sw);
     HIP_TRY(hipMalloc((void**)&st_out2, (size_t)B * g2.slots * 2 * 8));
     HIP_TRY(hipMemset(st_out2, 0, (size_t)B * g2.slots * 2 * 8));
     {   // deterministic pseudo-random fill (values ~U(-1,1)); split weights are packed as at load time
@@ -1323,6 +1403,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
         HIP_TRY(hipMemset(resid, 0, ndst * 4));
     }
     GemmArgs a{};
+    a.sw = sw;
     a.src = src; a.src_ld = Cin; a.wgt = wgt; a.wgt_frag = wfrag; a.split = split; a.dst = dst; a.dst_ld = Cout;
     a.M = M; a.K = Cin; a.N = Cout; a.taps = taps; a.H = H; a.W = W; a.HW = HW;
     if (row_ln) { a.H = 1; a.W = 1; a.HW = 1; }             // like Ctx::linear: every row is its own LayerNorm "sample"

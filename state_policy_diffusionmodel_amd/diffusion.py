@@ -165,7 +165,17 @@ class Diffusion_DDPM:
     # ==================== Sampling (models/diffusion_ddpm.py:223-277) ====================
     def sample(self, batch: Dict[str, torch.Tensor], option: Optional[str] = None, *,
                x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-               batched: bool = False, seed: int = 0, sample_offset: int = 0):
+               batched: bool = False, seed: Optional[int] = None, sample_offset: int = 0, every: int = 1):
+        """``option``: None -> x_0 (B,1,H,D); 'sample_history' -> list of the N+1 iterates (the reference's form);
+        'sample_history_stream' -> a generator of ``(i, x_i)`` host tensors handed out while the loop runs
+        (``every``: stride in steps; SpdmEngine.sample_stream).
+
+        ``seed``: key of the device noise stream that replaces the ``torch.randn`` diffusers' DDPM ``step`` draws from
+        the global generator on every step of every call.  None (default) draws a FRESH 62-bit seed per call from
+        torch's global generator -- so, as with the reference, two calls give different trajectories and
+        ``torch.manual_seed`` makes a run reproducible.  Ignored when ``noise`` is supplied."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         for key, tensor in batch.items():
             batch[key] = tensor.to(self.device)
         obs_cond = self.prepare_obs_cond_vectors(batch)                       # (B, obs_h, obs_dim)
@@ -182,6 +192,9 @@ class Diffusion_DDPM:
         spec.set_timesteps(self.noise_steps)                                  # :257/:268
         eng = self._engine_for(B, H, D)
         eng.set_scheduler(spec)
+        if option == "sample_history_stream":
+            return eng.sample_stream(obs_cond, x_T, noise=noise, inpaint=inpaint if self.inpaint_horizon > 0 else None,
+                                     seed=seed, sample_offset=sample_offset, every=every)
         want_hist = (option == "sample_history")
         res = eng.sample(obs_cond, x_T, noise=noise, inpaint=inpaint if self.inpaint_horizon > 0 else None,
                          seed=seed, sample_offset=sample_offset, history=want_hist)
@@ -228,11 +241,12 @@ class Diffusion_DDPM:
         return torch.cat([pos, act], dim=-1)
 
     def prepare_prediction_batch(self, batch):
-        """models/diffusion_ddpm.py:300-315: the last pred_horizon entries of every modality."""
+        """models/diffusion_ddpm.py:300-315: everything after the observed window, ``batch[k][:, self.obs_horizon:]``
+        (the dataset windows are obs_horizon + pred_horizon long, so this is the last pred_horizon entries)."""
         out = {}
         for k in ("image", "position", "action", "velocity", "image_features"):
             if k in batch:
-                out[k] = batch[k][:, self.obs_horizon:self.obs_horizon + self.pred_horizon].to(self.device).float()
+                out[k] = batch[k][:, self.obs_horizon:].to(self.device).float()
         return out
 
     def prepare_prediction_vectors(self, prediction_batch):

@@ -75,6 +75,23 @@ class SpdmEngine:
     def device_bytes(self) -> int:
         return int(self.lib.spdm_device_bytes(self._h))
 
+    @property
+    def demoted_tensors(self) -> int:
+        """Weight tensors outside the split format's range (|w| >= 511), kept on the exact fp32 kernels."""
+        return int(self.lib.spdm_demoted_tensors(self._h))
+
+    def set_switch(self, name: str, on: bool = True) -> None:
+        """Flip one kernel-selection switch (``SPDM_NO_GRAPH``, ``SPDM_NO_WIDE``, ...) on this handle.  The
+        environment is read once, at construction; this is the test / tuning hook for a live engine."""
+        _lib.check(self.lib.spdm_set_switch(self._h, name.encode(), int(bool(on))), "spdm_set_switch")
+
+    def nonfinite(self) -> bool:
+        """True if the last sampling loop / U-Net evaluation produced a non-finite value (synchronises the stream).
+        On the split-precision path this is how an activation beyond its range (|x| > 4094) shows."""
+        flag = ctypes.c_int32(0)
+        _lib.check(self.lib.spdm_nonfinite(self._h, ctypes.byref(flag), self._stream()), "spdm_nonfinite")
+        return bool(flag.value)
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -162,12 +179,57 @@ class SpdmEngine:
         return out
 
     def sample(self, cond, x_T, noise=None, inpaint=None, seed: int = 0, sample_offset: int = 0,
-               history: bool = False):
-        """x_0 (B,1,H,D); with history=True also the (n_steps+1,B,1,H,D) stack x_T..x_0."""
+               history: bool = False, check_finite: bool = True):
+        """x_0 (B,1,H,D); with history=True also the (n_steps+1,B,1,H,D) stack x_T..x_0.  Raises if an iterate left
+        the finite range (the split-precision contractions overflow beyond |activation| 4094: re-create the engine
+        with exact_fp32=True for such a model)."""
         hist = self.sample_begin(cond, x_T, noise, inpaint, seed, sample_offset, history)
         self.sample_run(0, self.n_steps)
         out = self.sample_result()
+        if check_finite and self.nonfinite():
+            raise FloatingPointError("non-finite iterate in the sampling loop" + (
+                ": an activation left the split-fp16 range (|x| < 4094); use exact_fp32=True" if self.split_precision else ""))
         return (out, hist) if history else out
+
+    def sample_stream(self, cond, x_T, noise=None, inpaint=None, seed: int = 0, sample_offset: int = 0, every: int = 1):
+        """Generator over the running loop: yields ``(i, x_i)`` -- the iterate after ``i`` denoise steps as a HOST tensor
+        (B,1,H,D) -- for i = 0, every, 2*every, ..., n_steps, WHILE the device keeps stepping: chunk k+1 is enqueued before
+        chunk k's snapshot is handed out, and snapshots travel on a side stream into pinned memory.  This is the streaming
+        form of ``option='sample_history'`` (models/diffusion_ddpm.py:256-265 builds the whole list first; its consumer,
+        utils/plot_utils.py:199-277, draws one frame per iterate)."""
+        if every < 1:
+            raise ValueError("every must be >= 1")
+        self.sample_begin(cond, x_T, noise, inpaint, seed, sample_offset, history=False)
+        main = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        pending = None                                     # (step index, pinned host tensor, copy-done event)
+
+        def snapshot(i):
+            dev_copy = self.sample_result()                # device-side copy, ordered behind step i on the loop's stream
+            ready = torch.cuda.Event()
+            ready.record(main)
+            host = torch.empty(dev_copy.shape, dtype=dev_copy.dtype, pin_memory=True)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                host.copy_(dev_copy, non_blocking=True)
+                dev_copy.record_stream(side)
+                done = torch.cuda.Event()
+                done.record(side)
+            return i, host, done
+
+        pending = snapshot(0)
+        i = 0
+        while i < self.n_steps:
+            j = min(self.n_steps, i + every)
+            self.sample_run(i, j)                          # asynchronous: the device works on [i, j) ...
+            nxt = snapshot(j)
+            pi, ph, pd = pending                           # ... while the caller consumes iterate i
+            pd.synchronize()
+            yield pi, ph
+            pending, i = nxt, j
+        pi, ph, pd = pending
+        pd.synchronize()
+        yield pi, ph
 
     # -- introspection ------------------------------------------------------------------------
     def debug_tensor(self, name: str) -> torch.Tensor:

@@ -21,12 +21,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"].startswith("f32")
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 64 * 1000.0 / d["ms_per_step"]) <= 1e-6 * d["value"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_frac",
+              "executed_mfma_frac", "hbm_frac", "hbm_bytes_per_step"):
         assert k in rf, k
+    assert rf["frac"] == rf["algorithmic_frac"]                      # `frac` is the ALGORITHMIC fraction (task contract)
+    assert abs(rf["executed_mfma_frac"] - 3.0 * rf["frac"]) <= 1e-9  # split path: 3 fp16 MFMAs per product
+    assert rf["traffic"] is None and rf["hbm_frac"] is None          # batch 64 is not the profiled geometry: no static figure
+    assert "B=64" in d["metric"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9 and 0.0 < rf["frac"] < 1.0
     cb = d["cpu_baseline"]

@@ -29,6 +29,39 @@ def test_oracle_matches_torch_modules_built_like_the_reference():
     assert torch.equal(got, want)
 
 
+def _golden():
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "encoder_n5.npz"))
+    sd = make_encoder_state_dict(int(g["wseed"]))
+    x = _images(int(g["n"]), int(g["iseed"]))
+    # the fixture stores checksums of the regenerated inputs / weights instead of 550 KB of frames
+    assert abs(float(x.double().sum()) - float(g["images_sum"])) <= 1e-6 * float(g["images_sum"])
+    np.testing.assert_array_equal(x[0, 0, 0].numpy(), g["first_image_row"])
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["weights_sum"])) <= 1e-9 + 1e-9 * abs(float(g["weights_sum"]))
+    return sd, x, g["latent"]
+
+
+def test_oracle_matches_reference_golden():
+    """tests/golden/encoder_n5.npz: output of the IMPORTED reference Autoencoder().encoder (tools/make_golden.py)."""
+    sd, x, want = _golden()
+    got = encoder_forward(sd, x).numpy()
+    assert got.shape == want.shape == (5, 128)
+    assert np.abs(got - want).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_encoder_matches_reference_golden():
+    from state_policy_diffusionmodel_amd.vision import VisionEncoder
+    sd, x, want = _golden()
+    enc = VisionEncoder(sd)
+    try:
+        got = enc(x.cuda()).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL
+    finally:
+        enc.close()
+
+
 def test_encoder_state_dict_extraction_from_checkpoint_key_styles():
     from state_policy_diffusionmodel_amd.vision import encoder_state_dict_from
     sd = make_encoder_state_dict(0)

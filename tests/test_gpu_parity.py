@@ -115,7 +115,8 @@ def test_unfused_fallbacks_match_fused_paths(monkeypatch):
 
 @pytest.mark.parametrize("H,D,B,attention,cond", [(24, 4, 5, True, True), (8, 1, 3, True, True),
                                                   (48, 8, 2, False, True), (16, 3, 4, True, False),
-                                                  (32, 3, 33, True, True)])
+                                                  (32, 3, 33, True, True), (32, 3, 96, True, True),
+                                                  (16, 3, 128, True, True)])
 def test_unet_matches_oracle_on_fresh_inputs(H, D, B, attention, cond):
     obs_h, obs_dim = 3, 11
     sd = weights(obs_h * obs_dim, 21, attention)
@@ -248,15 +249,19 @@ def test_device_philox_stream_matches_oracle_and_is_shard_invariant():
         eng.close()
 
 
-@pytest.mark.parametrize("B,H,D", [(4096, 32, 3), (1024, 64, 6), (1500, 16, 3)],
-                         ids=["config4_b4096_h32d3", "config5_geometry_b1024_h64d6", "b1500_h16d3"])
-def test_full_size_batch_properties(B, H, D):
+@pytest.mark.parametrize("B,H,D,kind", [(4096, 32, 3, "ddpm"), (1024, 64, 6, "ddpm"), (1500, 16, 3, "ddpm"),
+                                        (256, 32, 3, "ddpm"), (512, 32, 3, "ddpm"), (1024, 32, 3, "ddim"),
+                                        (1024, 64, 6, "ddim"), (512, 64, 6, "ddim")],
+                         ids=["config4_b4096_h32d3", "config5_geometry_b1024_h64d6", "b1500_h16d3",
+                              "config2_b256_h32d3", "config4_per_rank_b512_h32d3", "config3_ddim_b1024_h32d3",
+                              "config5_ddim_b1024_h64d6", "config5_per_rank_ddim_b512_h64d6"])
+def test_full_size_batch_properties(B, H, D, kind):
     """BASELINE.json's batches (4096 x horizon 32; horizon 64 x state_dim 6; plus a ragged one at horizon 16): too
     large for the CPU oracle in seconds, so check size-independent properties: each trajectory of the big batch
     (large-batch kernels: conv3x3_wide_kernel in all its variants) equals the same trajectory run in a small batch
     (the oracle-checked regime), inpainted rows are exact, output finite."""
-    from state_policy_diffusionmodel_amd.schedulers import DDPMScheduler
-    cd, T, N = 1350, 1000, 2
+    from state_policy_diffusionmodel_amd.schedulers import DDIMScheduler, DDPMScheduler
+    cd, T, N = 1350, (1000 if kind == "ddpm" else 50), 2
     sd = weights(cd, 0)
     g = torch.Generator().manual_seed(2)
     cond = torch.randn(B, 1, 10, 135, generator=g).cuda()
@@ -264,12 +269,13 @@ def test_full_size_batch_properties(B, H, D):
     inpaint = (torch.rand(B, 1, 1, D, generator=g) * 2 - 1).cuda()
     eng = make_engine(H, D, cd, B, sd, T=T)
     try:
-        s = DDPMScheduler(num_train_timesteps=T)
+        s = (DDPMScheduler if kind == "ddpm" else DDIMScheduler)(num_train_timesteps=T)     # DDIM: generate.py:28-35's reading
         s.set_timesteps(T)
         eng.set_scheduler(s)
         eng.sample_begin(cond, x_T, inpaint=inpaint, seed=3)
         eng.sample_run(0, N)
         big = eng.sample_result().cpu()
+        assert not eng.nonfinite()
         assert bool(torch.isfinite(big).all())
         assert torch.equal(big[:, :, :1, :], inpaint.cpu())
         idx = [0, 1, B // 2 - 1, B - 1]
@@ -300,11 +306,8 @@ def test_graph_replay_equals_plain_launches(monkeypatch):
         eng.set_scheduler(sched)
         res = {}
         for mode in ("graph", "plain"):
-            if mode == "plain":
-                monkeypatch.setenv("SPDM_NO_GRAPH", "1")
-            else:
-                monkeypatch.delenv("SPDM_NO_GRAPH", raising=False)
-            for seed in (3, 4):      # device Philox noise: the seed is baked into the step's arguments
+            eng.set_switch("SPDM_NO_GRAPH", mode == "plain")
+            for seed in (3, 4):      # device Philox noise: the seed lives in a device word, so both seeds replay ONE graph
                 x0, hist = eng.sample(cond, x_T, noise=None, inpaint=inpaint, seed=seed, history=True)
                 res[(mode, seed)] = (x0.cpu(), hist.cpu())
         for seed in (3, 4):
@@ -313,7 +316,6 @@ def test_graph_replay_equals_plain_launches(monkeypatch):
         if kind is DDPMScheduler:
             assert not torch.equal(res[("graph", 3)][0], res[("graph", 4)][0])
         eng.close()
-    monkeypatch.delenv("SPDM_NO_GRAPH", raising=False)
 
 
 def test_error_behaviour():
@@ -339,3 +341,73 @@ def test_error_behaviour():
             e2.load_state_dict({k: v for k, v in sd.items() if not k.startswith("sa3")})
         finally:
             e2.close()
+
+
+def test_split_range_guard_weights(monkeypatch):
+    """|w| >= 511 cannot be represented by the split-fp16 weight format (x 2^7 -> fp16 inf).  spdm_load_weights must keep
+    such a layer on the exact fp32 kernels: still the oracle's result, never inf.  One outlier each in a conv of the
+    wide kernel, a conv of the level-3 path, a Linear of the fused C = 64 attention block, of the C = 128 tail kernel,
+    of the C = 256 GEMM chain, a time-embedding Linear and a FiLM encoder."""
+    H, D, B, cd = 32, 3, 3, 33
+    base = weights(cd, 21)
+    sd = {k: v.copy() for k, v in base.items()}
+    hit = ["up3.doubleConv1.first.weight", "bot2.second.weight", "sa6.ff_self.1.weight", "sa1.attention.out_proj.weight",
+           "sa2.attention.in_proj_weight", "down2.emb_layer.1.weight", "up1.cond_encoder.2.weight"]
+    for i, k in enumerate(hit):
+        flat = sd[k].reshape(-1)
+        flat[(7 * i + 3) % flat.size] = 600.0 if i % 2 == 0 else -650.0
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 1, H, D, generator=g)
+    y = torch.randn(B, 1, 3, 11, generator=g)
+    t = torch.tensor([5, 400, 999])
+    want = unet_film_forward(sd, x, t, y).numpy()
+    eng = make_engine(H, D, cd, B, sd)
+    try:
+        assert eng.split_precision and eng.demoted_tensors >= len(hit)
+        got = eng.unet_forward(x.cuda(), t, y.cuda()).cpu().numpy()
+        assert np.isfinite(got).all() and not eng.nonfinite()
+        assert np.abs(got - want).max() <= TOL * max(1.0, np.abs(want).max())
+    finally:
+        eng.close()
+    eng = make_engine(H, D, cd, B, base)
+    try:
+        assert eng.demoted_tensors == 0
+    finally:
+        eng.close()
+
+
+def test_split_range_guard_activations():
+    """Activations beyond the split format's range (|x| > 4094) overflow to inf in the fp16 hi part.  The library must
+    say so (device flag -> FloatingPointError from sample(), nonfinite() after unet_forward) instead of returning
+    garbage with SPDM_OK; the exact-fp32 engine handles the same model."""
+    from state_policy_diffusionmodel_amd.schedulers import DDIMScheduler
+    H, D, B, cd = 16, 3, 2, 33
+    sd = {k: v.copy() for k, v in weights(cd, 21).items()}
+    for k in sd:                       # FiLM scale/bias x 3e5: the up-path activations leave the fp16 range
+        if "cond_encoder.2" in k:
+            sd[k] = sd[k] * 3.0e5
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 1, H, D, generator=g)
+    y = torch.randn(B, 1, 3, 11, generator=g)
+    want = unet_film_forward(sd, x, torch.tensor([7]), y).numpy()
+    assert np.isfinite(want).all()
+    eng = make_engine(H, D, cd, B, sd)
+    try:
+        got = eng.unet_forward(x.cuda(), [7], y.cuda()).cpu().numpy()
+        ok = np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+        assert ok or eng.nonfinite(), "silent garbage: neither correct nor flagged"
+        if not ok:
+            s = DDIMScheduler(num_train_timesteps=50)
+            s.set_timesteps(5)
+            eng.set_scheduler(s)
+            with pytest.raises(FloatingPointError):
+                eng.sample(y.cuda(), torch.rand(B, 1, H, D).cuda())
+    finally:
+        eng.close()
+    exact = make_engine(H, D, cd, B, sd, exact_fp32=True)
+    try:
+        got = exact.unet_forward(x.cuda(), [7], y.cuda()).cpu().numpy()
+        assert not exact.nonfinite()
+        assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+    finally:
+        exact.close()

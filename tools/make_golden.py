@@ -114,8 +114,44 @@ def trajectory_case(name, kind, T, N, H, D, B, obs_h=10, obs_dim=135, inp_h=1, w
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def encoder_case(name, n, wseed=5, iseed=11):
+    """The observation encoder (models/encoder/autoencoder.py:7-20): import the reference ``Autoencoder`` class -- its module
+    needs ``pytorch_lightning`` and ``torchvision`` only for names it never touches on this path (the LightningModule
+    base of the *training* wrapper, an unused ``models`` import), so both are stubbed exactly like ``torchvision`` above --
+    load OUR generated tensors into its ``.encoder`` with strict=True (pins the key inventory) and record its output."""
+    from oracle.encoder_ref import make_encoder_state_dict
+    if "pytorch_lightning" not in sys.modules:
+        pl = types.ModuleType("pytorch_lightning")
+        pl.LightningModule = torch.nn.Module          # base class of the training wrapper defined further down the file
+        sys.modules["pytorch_lightning"] = pl
+    tv = sys.modules.get("torchvision") or types.ModuleType("torchvision")
+    if not hasattr(tv, "models"):
+        tv.models = types.ModuleType("torchvision.models")
+    sys.modules["torchvision"] = tv
+    sys.modules.setdefault("torchvision.models", tv.models)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from models.encoder.autoencoder import Autoencoder
+    ae = Autoencoder()
+    sd = make_encoder_state_dict(wseed)
+    ae.encoder.load_state_dict(sd, strict=True)
+    ae.eval()
+    images = torch.rand(n, 3, 96, 96, generator=gen(iseed))          # frames are in [0,1]
+    with torch.no_grad():
+        latent = ae.encoder(images)
+    path = os.path.join(OUT, f"encoder_{name}.npz")
+    # images are regenerated from the seed by the tests (torch's CPU generator is deterministic); a checksum pins them
+    np.savez_compressed(path, n=n, wseed=wseed, iseed=iseed, latent=latent.numpy(),
+                        images_sum=np.float64(images.double().sum().item()), first_image_row=images[0, 0, 0].numpy(),
+                        weights_sum=np.float64(sum(v.double().sum().item() for v in sd.values())))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--encoder-only" in sys.argv:
+        encoder_case("n5", 5)
+        return
     torch.set_num_threads(8)
     # U-Net forward, the shape set of SURVEY.md section 8(c)
     forward_case("h16d3_b1", 16, 3, 1, 10, 135, [0, 1, 50, 99])
@@ -130,6 +166,7 @@ def main():
     trajectory_case("ddim_T10_h16d3_b2", "ddim", 10, 10, 16, 3, 2)
     trajectory_case("ddim_T100_n10_h32d3_b1", "ddim", 100, 10, 32, 3, 1)
     trajectory_case("ddpm_T12_h32d3_b2_inp4", "ddpm", 12, 12, 32, 3, 2, inp_h=4)
+    encoder_case("n5", 5)
 
 
 if __name__ == "__main__":
