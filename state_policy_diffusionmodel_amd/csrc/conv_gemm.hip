@@ -120,8 +120,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int mtile = logical / n_ntiles, ntile = logical - mtile * n_ntiles;
+    // split-K: workgroup (tile, ks) walks the chunks [kc0, kc1) only and leaves a raw partial tile (kernels.h)
+    const int ksp = a.ksplit > 1 ? a.ksplit : 1;
+    const int tiles_mn = nblk / ksp;
+    const int ks = logical / tiles_mn, tl = logical - ks * tiles_mn;
+    const int mtile = tl / n_ntiles, ntile = tl - mtile * n_ntiles;
     const int m0 = mtile * M_T, n0 = ntile * N_T;
+    const int kc0 = (int)((long long)ks * (K / CK) / ksp), kc1 = (int)((long long)(ks + 1) * (K / CK) / ksp);
 
     float* Abuf = smem;                                   // [NBA][QZ][LDK]
     float* Wbuf = Abuf + NBA * QZ * LDK;                  // [2][TPI][N_T][WROW]
@@ -232,10 +237,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 #define SPDM_LOAD_A(chunk_)                                                                         \
     {                                                                                               \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_)                                       \
-            areg[p_] = *reinterpret_cast<const f32x4*>(aptr[p_] + (chunk_) * CK);                   \
+            areg[p_] = *reinterpret_cast<const f32x4*>(aptr[p_] + (kc0 + (chunk_)) * CK);           \
         if (pro) {                                                                                  \
-            g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + (chunk_) * CK + c4 * 4);            \
-            b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (chunk_) * CK + c4 * 4);             \
+            g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + (kc0 + (chunk_)) * CK + c4 * 4);    \
+            b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (kc0 + (chunk_)) * CK + c4 * 4);     \
         }                                                                                           \
     }
     const int gw = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, provably uniform
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
         _Pragma("unroll") for (int blk_ = 0; blk_ < TPI * N_T / 32; ++blk_) {                      \
             const int row0_ = (blk_ * 4 + gw) * 8;                 /* wave-uniform */               \
             const int tp_ = row0_ / N_T, n_ = row0_ % N_T;                                          \
-            const float* sb_ = a.wgt + (size_t)(((tg_) * TPI + tp_) * N + n0 + n_) * K + (chunk_) * CK; \
+            const float* sb_ = a.wgt + (size_t)(((tg_) * TPI + tp_) * N + n0 + n_) * K + (kc0 + (chunk_)) * CK; \
             float* dst_ = Wbuf + (buf_) * TPI * N_T * WROW + row0_ * 32;                            \
             __builtin_amdgcn_global_load_lds(                                                       \
                 (const __attribute__((address_space(1))) void*)(sb_ + dma_loff),                    \
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 #define SPDM_LOAD_W(chunk_, tg_)                                                                    \
     if (!WDMA) {                                                                                    \
         _Pragma("unroll") for (int tp_ = 0; tp_ < TPI; ++tp_) {                                    \
-            const float* wb_ = wptr + (size_t)((tg_) * TPI + tp_) * N * K + (chunk_) * CK;          \
+            const float* wb_ = wptr + (size_t)((tg_) * TPI + tp_) * N * K + (kc0 + (chunk_)) * CK;  \
             _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                   \
                 wreg[tp_ * WPASS + p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * RP * K); \
         }                                                                                           \
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
         }                                                                                           \
     }
 
-    const int nchunks = K / CK;
+    const int nchunks = kc1 - kc0;            // chunk indices below are relative to kc0
     const int ngroups = taps / TPI;
     const int niter = nchunks * ngroups;
 
@@ -541,7 +546,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             }
         }
 
-    if (a.epi == EPI_STATS) {
+    const int epi = (ksp > 1) ? EPI_PLAIN : a.epi;                       // split-K: raw partial tile only
+    float* const dstp = (ksp > 1) ? a.partial + (size_t)ks * M * N : a.dst;
+    const int dst_ld = (ksp > 1) ? N : a.dst_ld;
+    if (epi == EPI_STATS) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     __syncthreads();
     SPDM_STAMP()
 
-    if (a.epi == EPI_STATS) {
+    if (epi == EPI_STATS) {
         const int t_lo = m0, t_hi = min(m0 + M_T, M);
         if (t_hi > t_lo) {
             const int b_first = t_lo / HW, b_last = (t_hi - 1) / HW;
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     {
         constexpr int TPR = N_T / 4, RPP = NTHR / TPR;    // threads per row, rows per pass
         const int c4o = tid % TPR, r0 = tid / TPR;
-        const bool has_bias = (a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID);
+        const bool has_bias = (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID);
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
         if (has_bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + c4o * 4);
 #pragma unroll 4
@@ -623,12 +631,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             if (row < M && !(dbg & DBG_NO_STORE)) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(otile + row_l * N_T + c4o * 4);
                 v += bias4;
-                if (a.epi == EPI_BIAS_GELU) {
+                if (epi == EPI_BIAS_GELU) {
                     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                 }
-                if (a.epi == EPI_BIAS_RESID)
+                if (epi == EPI_BIAS_RESID)
                     v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.resid_ld + n0 + c4o * 4);
-                *reinterpret_cast<f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4o * 4) = v;
+                *reinterpret_cast<f32x4*>(dstp + (size_t)row * dst_ld + n0 + c4o * 4) = v;
                 if (a.row_stats != nullptr) {   // LayerNorm partials of the consumer: the row sits on TPR consecutive lanes
                     float s1 = (v.x + v.y) + (v.z + v.w);
                     float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -660,7 +668,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 // Tile choice is occupancy-aware: the 8-wave 256-row configuration only when it still yields enough
 // workgroups to cover the 256 CUs; otherwise 128-row tiles, and 64-wide instead of 128-wide tiles when even
 // those would leave CUs idle (small batches / coarse levels).
-GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split, unsigned sw) {
+// tuning knobs for experiments (SPDM_TUNE0.. read once per process; defaults = the measured choice)
+int spdm_tune(int idx, int dflt) {
+    static int val[8];
+    static bool have[8], init = false;
+    if (!init) {
+        for (int i = 0; i < 8; ++i) {
+            char name[16];
+            snprintf(name, sizeof(name), "SPDM_TUNE%d", i);
+            const char* e = getenv(name);
+            have[i] = e != nullptr;
+            val[i] = e ? atoi(e) : 0;
+        }
+        init = true;
+    }
+    return (idx >= 0 && idx < 8 && have[idx]) ? val[idx] : dflt;
+}
+
+GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, bool stats_epi) {
     GemmGeom g;
     const int nt128 = (N % 128 == 0) ? N / 128 : 0;
     const int nt_pref = nt128 ? nt128 : N / 64;
@@ -678,7 +703,52 @@ GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split, unsigned sw) {
         !(sw & SW_NO_T512) && ((HW & 3) != 0 || (sw & SW_T512)))
         g.m_tile = 512;
     g.n_tiles = N / g.n_tile;
-    g.slots = stats_slots(HW, g.m_tile, g.n_tiles);
+    g.ksplit = 1;
+    // Split-K: a grid that leaves most CUs idle (small batches; the coarse levels at medium batches) is a few long serial
+    // K loops, each paced by one weight round trip per iteration.  Split the 32-channel chunks over ksplit x as many
+    // workgroups (partial slabs + launch_splitk_combine, kernels.h) until the grid reaches ~one workgroup per CU.
+    const bool may_split = stats_epi && split && taps != 1 && K % CK == 0 && !(sw & SW_NO_SPLITK);
+    // Width-2 maps (level 2): the 256-row kernels skip the zero-padding taps (a third of the MFMAs) and read half the weight
+    // bytes per MFMA; keep that tiling and let split-K restore the grid (measured at B = 256 / 512 / 1024 on up1.dc1:
+    // 83 -> 63, 126 -> 100 us; on width-4 maps the same trade LOSES 5-10 us per layer, so only here)
+    if (may_split && !big && split && taps == 9 && W == 2 && (HW & 7) == 0 && M >= 256 && K % 64 == 0 && spdm_tune(2, 1) != 0) {
+        const long long t256 = (long long)((M + 255) / 256) * nt_pref;
+        const int target = spdm_tune(0, 256);
+        int S = (int)std::min<long long>(K / 64, (target + t256 - 1) / t256);
+        while (S > 1 && (size_t)S * M * N * sizeof(float) > SPLITK_WORKSPACE_BYTES) --S;
+        if (t256 * S >= target * 3 / 4 && S <= spdm_tune(3, 4)) {
+            g.m_tile = 256; g.n_tile = nt128 ? 128 : 64; g.n_tiles = N / g.n_tile; g.ksplit = S;
+            g.st_m_tile = combine_rows(HW, N); g.st_n_tiles = 1;
+            g.slots = stats_slots(HW, g.st_m_tile, g.st_n_tiles);
+            return g;
+        }
+    }
+    if (may_split && !big) {
+        const int nchunks = K / CK;
+        const int target = spdm_tune(0, 256);
+        // with split-K available, 128-wide tiles (conv_wide.hip's 128-row variant: weights straight from L2 into registers)
+        // no longer need to be narrowed to fill the chip
+        // (measured the other way round: 64-wide conv_gemm tiles + split-K beat 128-wide conv_wide tiles + split-K at every
+        //  batch from 1 to 512 -- 540 vs 629 us per step at B = 1 -- so this preference stays an experiment, SPDM_TUNE1=1)
+        const bool wide128 = nt128 && (HW & 3) == 0 && K % 64 == 0 && !(sw & (SW_NO_WIDE | SW_NO_WIDE128)) && spdm_tune(1, 0) != 0;
+        const long long mt = (M + 127) / 128;
+        if (wide128 && mt * nt128 < target) g.n_tile = 128, g.n_tiles = nt128;
+        const long long tiles = mt * g.n_tiles;
+        if (tiles < target) {
+            const int unit = (g.n_tile == 128 && wide128) ? 2 : 1;        // chunks per split step (the wide kernel walks taps in pairs)
+            int S = (int)std::min<long long>(nchunks / unit, (target + tiles - 1) / tiles);
+            while (S > 1 && (size_t)S * M * N * sizeof(float) > SPLITK_WORKSPACE_BYTES) --S;
+            if (S > 1) g.ksplit = S;
+        }
+    }
+    if (g.ksplit > 1) {          // the combine kernel writes the statistics
+        g.st_m_tile = combine_rows(HW, N);
+        g.st_n_tiles = 1;
+    } else {
+        g.st_m_tile = g.m_tile;
+        g.st_n_tiles = g.n_tiles;
+    }
+    g.slots = stats_slots(HW, g.st_m_tile, g.st_n_tiles);
     return g;
 }
 
@@ -687,7 +757,7 @@ static bool uses_w2(const GemmArgs& a, const GemmGeom& g) {
     return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && !(a.sw & SW_NO_W2);
 }
 double gemm_flops(const GemmArgs& a) {
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split, a.sw);
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS);
     const double taps = uses_w2(a, g) ? 6.0 : (double)a.taps;
     return 2.0 * (double)a.M * (double)a.N * (double)a.K * taps;
 }
@@ -711,12 +781,27 @@ static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s
     auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI, W2>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
-    const int grid = n_mtiles * g.n_tiles;
+    const int grid = n_mtiles * g.n_tiles * std::max(a.ksplit, 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, g.slots);
     return hipGetLastError();
 }
 
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipStream_t s);
+
+hipError_t launch_gemm(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.ksplit = 1;
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    if (g.ksplit > 1) {
+        if ((size_t)g.ksplit * a.M * a.N * sizeof(float) > SPLITK_WORKSPACE_BYTES || a.dst_ld != a.N) return hipErrorInvalidValue;
+        a.ksplit = g.ksplit;
+        if (hipError_t e = launch_gemm_kernel(a, g, s); e != hipSuccess) return e;
+        return launch_splitk_combine(a.partial, g.ksplit, a.dst, a.M, a.N, a.HW, a.epi_stats, s);
+    }
+    return launch_gemm_kernel(a, g, s);
+}
+
+static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     // shape contract of the kernel -- checked on the host so that a bad plan can never fault the GPU
     if (a.M <= 0 || a.K <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (a.K % CK != 0 || a.N % 64 != 0) return hipErrorInvalidValue;
@@ -731,7 +816,6 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.epi == EPI_STATS && a.epi_stats == nullptr) return hipErrorInvalidValue;
     if ((a.epi == EPI_BIAS || a.epi == EPI_BIAS_GELU || a.epi == EPI_BIAS_RESID) && a.bias == nullptr) return hipErrorInvalidValue;
     if (a.epi == EPI_BIAS_RESID && a.resid == nullptr) return hipErrorInvalidValue;
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.HW, a.taps, a.split, a.sw);
     if (a.split) {
         if (a.taps == 1) {
             if (g.n_tile == 128) return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 2, 1>(a, g, s);

@@ -115,8 +115,14 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int mtile = logical / n_ntiles, ntile = logical - mtile * n_ntiles;
+    // split-K: workgroup (tile, ks) walks the chunks [kc0, kc1) (host: K % 64 == 0)
+    const int ksp = a.ksplit > 1 ? a.ksplit : 1;
+    const int tiles_mn = nblk / ksp;
+    const int ks = logical / tiles_mn, tl = logical - ks * tiles_mn;
+    const int mtile = tl / n_ntiles, ntile = tl - mtile * n_ntiles;
     const int m0 = mtile * M_T, n0 = ntile * N_T;
+    // even chunk ranges: the flat (chunk, tap) sequence of the tap-pair loop must have even length
+    const int kc0 = 2 * (int)((long long)ks * (K / (2 * CK)) / ksp), kc1 = (ksp > 1) ? 2 * (int)((long long)(ks + 1) * (K / (2 * CK)) / ksp) : K / CK;
 
     float* Abuf = smem;                       // [QZ][LDK]
     float* smean = Abuf + QZ * LDK;           // [NS]
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         acc[rt_][(ct0_) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[fas_][1], fb[fbs_][1][0], acc[rt_][(ct0_) + 1], 0, 0, 0); \
     }
 
-    const int nrows = nchunks * 3;            // loop trips: one kernel row (3 taps) of one chunk each
+    const int nrows = (kc1 - kc0) * 3;        // loop trips: one kernel row (3 taps) of one chunk each
     f16x8 fa[FAR][2], fb[FBR][2][2];
     // slab-row shift (floats) of tap (kernel row kr_, column index dwi_ = dw + 1)
 #define WIDE_SHIFT(kr_, dwi_) ((((kr_) - 1) * W + ((dwi_) - 1)) * LDK)
@@ -318,14 +324,14 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         const bool t3 = (TAPS == 3);
 #define TAP_SHIFT(tap_) (t3 ? ((tap_) - 1) * W * LDK : (((tap_) / 3 - 1) * W + ((tap_) - ((tap_) / 3) * 3 - 1)) * LDK)
 #define TAP_BIT(tap_) (t3 ? 3 * (tap_) + 1 : (tap_))
-        const int ntaps = nchunks * TAPS;
-        TAP_LOAD_B(0, 0, 0)
-        WIDE_LOAD_A(0)
+        const int ntaps = (kc1 - kc0) * TAPS;
+        TAP_LOAD_B(0, kc0, 0)
+        WIDE_LOAD_A(kc0)
         WIDE_STAGE_A()
         __syncthreads();
         WIDE_STAMP(2)
         TAP_LOAD_FA(0, TAP_BIT(0), TAP_SHIFT(0), 0)
-        int chunk = 0, tap = 0;
+        int chunk = kc0, tap = 0;
         for (int tt = 0; tt < ntaps; tt += 2) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -371,14 +377,14 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef TAP_BIT
     } else if constexpr (!W2) {
         // phase ph of a kernel row: tap column ph / NT, column-tile pair ph % NT
-        WIDE_LOAD_B(0, 0, 0, 0)
-        WIDE_LOAD_A(0)
+        WIDE_LOAD_B(0, kc0, 0, 0)
+        WIDE_LOAD_A(kc0)
         WIDE_STAGE_A()
         __syncthreads();
         WIDE_STAMP(2)
         WIDE_LOAD_FA(0, 0, WIDE_SHIFT(0, 0), 0)
         WIDE_LOAD_FA(1, 0, WIDE_SHIFT(0, 0), 1)
-        int chunk = 0, kr = 0;
+        int chunk = kc0, kr = 0;
         for (int r = 0; r < nrows; ++r) {
             int nkr = kr + 1, nchunk = chunk;
             if (nkr == 3) { nkr = 0; nchunk = chunk + 1; }
@@ -423,14 +429,14 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         // tiles, dw = -1 on the odd tiles: 32 tile steps instead of 48, only all-zero products dropped.
         //   step q:  0..7 (centre, pair 0)   8..15 (centre, pair 1)   16..19 / 20..23 (+1, even tiles, pair 0 / 1)
         //            24..27 / 28..31 (-1, odd tiles, pair 0 / 1)
-        WIDE_LOAD_B(0, 0, 1, 0)
-        WIDE_LOAD_A(0)
+        WIDE_LOAD_B(0, kc0, 1, 0)
+        WIDE_LOAD_A(kc0)
         WIDE_STAGE_A()
         __syncthreads();
         WIDE_STAMP(2)
         WIDE_LOAD_FA(0, 1, WIDE_SHIFT(0, 1), 0)
         WIDE_LOAD_FA(1, 1, WIDE_SHIFT(0, 1), 1)
-        int chunk = 0, kr = 0;
+        int chunk = kc0, kr = 0;
         for (int r = 0; r < nrows; ++r) {
             int nkr = kr + 1, nchunk = chunk;
             if (nkr == 3) { nkr = 0; nchunk = chunk + 1; }
@@ -512,6 +518,9 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     // accumulator layout: lane (l16, kg), register j of tile (rt, ct) = row 16 rt + 4 kg + j, column 16 ct + l16
     constexpr int NH = W2 ? 2 : WIDE_NH;                 // the tile leaves in NH parts (RW / NH rows of each wave per part)
     constexpr int HROWS = M_T / NH;
+    const bool partial_out = ksp > 1;                    // split-K: raw partial tile to the workspace, statistics by the combine kernel
+    float* const dstp = partial_out ? a.partial + (size_t)ks * M * N : a.dst;
+    const int dst_ld = partial_out ? N : a.dst_ld;
     float* otile = smem;                                 // [HROWS][N_T]
     float* srow = smem + HROWS * N_T;                    // [M_T / 4][WN][2]
 #pragma unroll
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         }
         __syncthreads();
         if (h == 0) WIDE_STAMP(4)
-        if (h == 0) {
+        if (h == 0 && !partial_out) {
             const int t_lo = m0, t_hi = min(m0 + M_T, M);
             const int ups = HW >> 2;                                   // 4-row units per sample
             const bool whole = (HW % M_T == 0);                        // the tile lies inside one sample
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
             const int row = m0 + (lr / (RW / NH)) * RW + h * (RW / NH) + lr % (RW / NH);
             if (row < M) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(otile + lr * N_T + c4o * 4);
-                *reinterpret_cast<f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4o * 4) = v;
+                *reinterpret_cast<f32x4*>(dstp + (size_t)row * dst_ld + n0 + c4o * 4) = v;
             }
         }
     }
@@ -635,7 +644,8 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
-    hipLaunchKernelGGL(kern, dim3(n_mtiles * g.n_tiles), dim3(NTHR), lds, s, a, g.slots, NS);
+    if (a.ksplit > 1 && a.K % 64 != 0) return hipErrorInvalidValue;          // split-K walks even chunk ranges
+    hipLaunchKernelGGL(kern, dim3(n_mtiles * g.n_tiles * std::max(a.ksplit, 1)), dim3(NTHR), lds, s, a, g.slots, NS);
     return hipGetLastError();
 }
 
@@ -651,6 +661,7 @@ bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
                         a.epi == EPI_STATS && a.row_stats == nullptr && a.K % CK == 0 &&
                         (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD)) == 0 && !(a.sw & SW_NO_WIDE);
     if (!common) return false;
+    if (a.ksplit > 1 && a.K % 64 != 0) return false;      // split-K walks even chunk ranges
     if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > 128) return false;       // 7-bit packed sample index per staging pass
     if (g.m_tile == 128)            // small tiles: the tap-pair loop only (128-wide, taps walked in pairs)
         return g.n_tile == 128 && (a.taps == 9 || (a.taps == 3 && a.W == 1)) && a.K % 64 == 0 && !(a.sw & SW_NO_WIDE128);

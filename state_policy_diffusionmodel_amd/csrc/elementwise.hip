@@ -487,6 +487,65 @@ hipError_t launch_out_step(const StepArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------------------------
+// Split-K combine (kernels.h): dst = sum over ks (ascending: deterministic) of the partial slabs a split-K implicit-GEMM
+// launch left, plus the GroupNorm(1,C) partial sums of dst -- the epilogue the GEMM itself could not run on partial
+// sums.  One workgroup = `rows` consecutive rows of ONE sample x all N channels (a contiguous run of rows * N floats);
+// per-thread fp32 sums of <= 32 values -> fp64 -> fixed-order reduction.
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ partial, int ksplit, size_t slab,
+                                                             float* __restrict__ dst, int N, int HW, int rows,
+                                                             double* __restrict__ stats, int slots) {
+    __shared__ double red[2][4];
+    const int per_sample = HW / rows;
+    const int b = blockIdx.x / per_sample, r = blockIdx.x - b * per_sample;
+    const size_t base = ((size_t)b * HW + (size_t)r * rows) * N;
+    const int n4 = rows * N / 4;
+    double d1 = 0.0, d2 = 0.0;
+    for (int i0 = 0; i0 < n4; i0 += 256 * 8) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * 256 + threadIdx.x;
+            if (i < n4) {
+                const float* p = partial + base + (size_t)i * 4;
+                float4 v = *reinterpret_cast<const float4*>(p);
+                for (int k = 1; k < ksplit; ++k) {
+                    const float4 w = *reinterpret_cast<const float4*>(p + (size_t)k * slab);
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+                *reinterpret_cast<float4*>(dst + base + (size_t)i * 4) = v;
+                s1 += (v.x + v.y) + (v.z + v.w);
+                s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
+        d1 += (double)s1;
+        d2 += (double)s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        d1 += __shfl_xor(d1, o, 64);
+        d2 += __shfl_xor(d2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d1; red[1][threadIdx.x >> 6] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = stats + ((size_t)b * slots + r) * 2;       // slot of tile mt = b HW / rows + r: (mt - b HW / rows) * 1 + 0
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+hipError_t launch_splitk_combine(const float* partial, int ksplit, float* dst, int M, int N, int HW, double* stats,
+                                 hipStream_t s) {
+    if (!partial || !dst || !stats || ksplit < 2 || M <= 0 || N % 4 != 0 || HW < 1 || M % HW != 0) return hipErrorInvalidValue;
+    const int rows = combine_rows(HW, N);
+    if (HW % rows != 0) return hipErrorInvalidValue;
+    const int B = M / HW;
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)(B * (HW / rows))), dim3(256), 0, s, partial, ksplit,
+                       (size_t)M * N, dst, N, HW, rows, stats, stats_slots(HW, rows, 1));
+    return hipGetLastError();
+}
+
 // loop bookkeeping kept on the device so that one denoise step is the same launch sequence for
 // every iteration (hipGraph-replayable): step <- step + 1, t <- timesteps[step]
 __global__ void advance_kernel(int* step_dev, int* t_dev, const int* timesteps, int n_steps, int set_to) {

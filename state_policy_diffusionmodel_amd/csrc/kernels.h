@@ -86,6 +86,11 @@ struct GemmArgs {
     int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
     int epi;  double* epi_stats;   const float* bias;  const float* resid;  int resid_ld;
     double* row_stats;                 // optional: per-row {sum, sum^2} of the STORED values, [row][n_tiles][2] (LayerNorm of the consumer)
+    // Split-K (small grids: few rows, long K).  ksplit > 1: the launch has ksplit x as many workgroups; workgroup (tile, ks)
+    // walks the 32-channel chunks [ks nchunks / ksplit, (ks + 1) nchunks / ksplit) of every tap and stores its raw fp32
+    // partial tile to partial[ks][M][N]; no statistics, no dst.  launch_splitk_combine then adds the slabs in the fixed
+    // order ks = 0, 1, ... (deterministic: no atomics), writes dst and the GroupNorm partial sums.
+    int ksplit;  float* partial;
     unsigned sw;                       // kernel-selection switches (SW_*) of the owning handle
     int debug;                         // ablation knobs for spdm_bench_gemm only (0 in the product path)
     unsigned long long* stamps;        // DBG_STAMP: [2][128] s_memtime stamps of one workgroup (diagnostic builds of the bench)
@@ -93,8 +98,27 @@ struct GemmArgs {
 enum { DBG_NO_MFMA = 1, DBG_NO_WLOAD = 2, DBG_NO_GELU = 4, DBG_NO_STORE = 8, DBG_NO_ALOAD = 16, DBG_PP = 64, DBG_STAMP = 128 };
 
 // geometry of the stats the GEMM writes (EPI_STATS)
-struct GemmGeom { int m_tile, n_tile, n_tiles, slots; };
-GemmGeom gemm_geometry(int M, int N, int HW, int taps, int split, unsigned sw);
+struct GemmGeom {
+    int m_tile, n_tile, n_tiles;     // output tile of the GEMM kernel
+    int slots;                       // statistics slots per sample of whoever writes them
+    int ksplit;                      // > 1: split-K launch + combine
+    int st_m_tile, st_n_tiles;       // StatsRef geometry of the statistics (the GEMM's own tiling, or the combine kernel's)
+};
+// K = input channels (per tap); ksplit is only ever > 1 for split-precision 3x3 / 3x1 convolutions with the statistics
+// epilogue (the callers that pass stats_epi = true)
+GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, bool stats_epi = false);
+constexpr size_t SPLITK_WORKSPACE_BYTES = (size_t)48 << 20;     // partial slabs of one launch (handle-owned buffer)
+// rows of one sample a combine workgroup owns (a power-of-two fraction of HW; <= 2048 values = two 16-byte pieces per thread
+// where HW allows: at batch 1 the combine is a handful of workgroups, so each must be short)
+__host__ __device__ inline int combine_rows(int HW, int N) {
+    int r = HW;
+    while ((r & 1) == 0 && (long long)r * N > 2048) r >>= 1;
+    return r;
+}
+// dst[m][n] = sum_ks partial[ks][m][n] (ks ascending) + GroupNorm partial sums in the layout StatsRef{slots = HW / rows + 1,
+// m_tile = rows, n_tiles = 1} with rows = combine_rows(HW, N)
+hipError_t launch_splitk_combine(const float* partial, int ksplit, float* dst, int M, int N, int HW, double* stats,
+                                 hipStream_t s);
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 // conv_wide.hip: the 4-wave / 128x64-per-wave configuration of the 3x3 implicit GEMM (256 x 128 tiles, two

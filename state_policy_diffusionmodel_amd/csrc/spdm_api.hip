@@ -155,6 +155,7 @@ struct spdm_handle {
     float* d_condm = nullptr;             // Mish(cond), K padded
     float* d_film[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* d_x = nullptr;                 // current iterate (B,H0,D)
+    float* d_partial = nullptr;           // split-K partial slabs of the launch in flight (SPLITK_WORKSPACE_BYTES)
     bool have_film = false;
     // sampling session
     int sB = 0, s_inp_h = 0, s_inp_per_sample = 0;
@@ -345,6 +346,7 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
         for (int i = 0; i < 6 && !rc; ++i) rc = dev_alloc(h, (void**)&h->d_film[i], sizeof(float) * (size_t)mb * 2 * film_c[i]);
         if (rc) break;
         if ((rc = dev_alloc(h, (void**)&h->d_x, sizeof(float) * (size_t)mb * H0 * D))) break;
+        if (h->split && !(h->sw & SW_NO_SPLITK) && (rc = dev_alloc(h, (void**)&h->d_partial, SPLITK_WORKSPACE_BYTES))) break;
         // size the arena with a dry run of the plan at max_batch
         h->arena.dry = true;
         h->arena.keep = (cfg->flags & SPDM_FLAG_DEBUG_KEEP) != 0;
@@ -742,8 +744,9 @@ struct Ctx {
         StatsBuf sb;
         const int slots = stats_slots(HW, m_tile, n_tiles);
         // reserve for the finest tiling any batch size can select (gemm_geometry is batch-dependent, the
-        // dry run that sizes the arena is not): 128-row x 64-wide tiles
-        const int slots_max = std::max(slots, stats_slots(HW, 128, std::max(1, C / 64)));   // (coarser tilings need fewer)
+        // dry run that sizes the arena is not): 128-row x 64-wide tiles, or the split-K combine kernel's row groups
+        const int slots_max = std::max(std::max(slots, stats_slots(HW, 128, std::max(1, C / 64))),   // (coarser tilings need fewer)
+                                       stats_slots(HW, combine_rows(HW, C), 1));
         size_t off = 0;
         if (!h->arena.alloc(sizeof(double) * 2 * (size_t)B * slots_max, &off)) {
             if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
@@ -779,9 +782,9 @@ struct Ctx {
         // by shape before the weights are known (the dry run at create); afterwards a tensor outside the split format's
         // range has no split copy and stays on the exact fp32 kernel (Loader::conv)
         const int split = (h->split && w.cin % 32 == 0 && (!h->weights_loaded || w.ws)) ? 1 : 0;
-        const GemmGeom g = gemm_geometry(M, w.cout, HW, w.taps, split, h->sw);
+        const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, split, h->sw, /*stats_epi=*/h->d_partial != nullptr);
         out.t = talloc(w.cout, level);
-        out.st = salloc(HW, w.cout, g.m_tile, g.n_tiles);
+        out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
         out.gamma = gamma; out.beta = beta;
         if (err || dry) return out;
         GemmArgs a{};
@@ -795,6 +798,7 @@ struct Ctx {
         a.pro = in.pending_gn() ? (gelu ? PRO_GN_GELU : PRO_GN) : PRO_NONE;
         if (in.pending_gn()) { a.pro_stats = in.st.ref; a.pro_gamma = in.gamma; a.pro_beta = in.beta; }
         a.epi = EPI_STATS; a.epi_stats = out.st.p;
+        a.partial = h->d_partial;            // non-null: launch_gemm may split K (small grids)
         if (in.t.C != w.cin) { if (!err) err = fail(SPDM_ERR_INVALID, "plan: conv input has %d channels, weight expects %d", in.t.C, w.cin); return out; }
         // Profiling (spdm_profile_*): HIP events on the launch stream.  Runs of CONSECUTIVE conv launches (the two
         // DoubleConvolutions of a block: nothing else is launched in between) share one event pair -- every event
@@ -903,7 +907,7 @@ struct Ctx {
             return out;
         }
         Tensor av = talloc(C, level);
-        const int nt_av = gemm_geometry(rows, C, 1, 1, (h->split && w.out_proj.ws) ? 1 : 0, h->sw).n_tiles;   // n-tiles of the out_proj GEMM
+        const int nt_av = gemm_geometry(rows, C, C, 1, 1, 1, (h->split && w.out_proj.ws) ? 1 : 0, h->sw).n_tiles;   // n-tiles of the out_proj GEMM
         StatsBuf avs = row_stats_alloc(rows, C, nt_av);
         linear(att.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p, nullptr, nullptr, nullptr, avs.p);
         free(att);
@@ -1350,7 +1354,8 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     HIP_TRY(hipSetDevice(device));
     const int HW = H * W, M = B * HW;
     const unsigned sw = switches_from_env();
-    const GemmGeom g = gemm_geometry(M, Cout, HW, taps, split, sw);
+    const bool may_splitk = split && epi == EPI_STATS && !(sw & SW_NO_SPLITK);
+    const GemmGeom g = gemm_geometry(M, Cout, Cin, HW, W, taps, split, sw, may_splitk);
     float *src = nullptr, *wgt = nullptr, *wgt32 = nullptr, *dst = nullptr, *dst2 = nullptr, *gb = nullptr, *resid = nullptr, *wfrag = nullptr;
     double *st_in = nullptr, *st_out = nullptr, *st_out2 = nullptr;
     const size_t nsrc = (size_t)M * Cin, nw = (size_t)taps * Cout * Cin, ndst = (size_t)M * Cout;
@@ -1365,7 +1370,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     HIP_TRY(hipMalloc((void**)&st_in, (size_t)(row_ln ? M : B) * 2 * 8));
     HIP_TRY(hipMalloc((void**)&st_out, (size_t)B * g.slots * 2 * 8));
     HIP_TRY(hipMemset(st_out, 0, (size_t)B * g.slots * 2 * 8));
-    const GemmGeom g2 = gemm_geometry(M, Cout, HW, taps, 0, sw);
+    const GemmGeom g2 = gemm_geometry(M, Cout, Cin, HW, W, taps, 0, sw);
     HIP_TRY(hipMalloc((void**)&st_out2, (size_t)B * g2.slots * 2 * 8));
     HIP_TRY(hipMemset(st_out2, 0, (size_t)B * g2.slots * 2 * 8));
     {   // deterministic pseudo-random fill (values ~U(-1,1)); split weights are packed as at load time
@@ -1414,6 +1419,11 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
     a.pro_gamma = gb; a.pro_beta = gb + Cin;
     a.epi = epi; a.epi_stats = st_out; a.bias = gb + 2 * Cin; a.resid = resid; a.resid_ld = Cout;
     a.debug = debug;
+    float* d_part = nullptr;
+    if (may_splitk) {
+        HIP_TRY(hipMalloc((void**)&d_part, SPLITK_WORKSPACE_BYTES));
+        a.partial = d_part;
+    }
     unsigned long long* d_stamps = nullptr;
     if (debug & DBG_STAMP) {
         HIP_TRY(hipMalloc((void**)&d_stamps, (size_t)65536 * 8 * 8));      // conv_wide: 8 stamps per workgroup
@@ -1486,7 +1496,7 @@ extern "C" int spdm_bench_gemm(int32_t device, int32_t B, int32_t H, int32_t W, 
         }
         (void)hipFree(d_stamps);
     }
-    (void)hipFree(wgt32); (void)hipFree(dst2); (void)hipFree(wfrag);
+    (void)hipFree(wgt32); (void)hipFree(dst2); (void)hipFree(wfrag); (void)hipFree(d_part);
     (void)hipFree(src); (void)hipFree(wgt); (void)hipFree(dst); (void)hipFree(resid); (void)hipFree(gb); (void)hipFree(st_in); (void)hipFree(st_out); (void)hipFree(st_out2);
     if (e != hipSuccess) return fail(SPDM_ERR_HIP, "bench_gemm: %s", hipGetErrorString(e));
     *ms_out = ms / iters;
