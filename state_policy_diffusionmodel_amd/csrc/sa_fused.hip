@@ -190,9 +190,13 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     const int tc = min(t, L - 1);
     const float* xrow = a.x + ((size_t)b * L + tc) * SA_C;
 
-    // zero rows 16..31 of V^T once (never overwritten): the d = 16 heads fill only half of a 32-row A tile
+    // rows 16..31 of V^T are written once (never overwritten): the d = 16 heads fill only half of a 32-row A tile.  Rows 16
+    // and 20 are all ONES (hi part), the rest zero: the P.V product then leaves sum_keys p in accumulator register 8 of both
+    // lane halves (row (r&3) + 8 (r>>2) + 4 kh) -- the softmax denominator comes out of the matrix pipe, which idles in this
+    // VALU-bound loop, instead of 16 adds per key block; the running rescale by alpha covers it like every other row.
     for (int i = tid; i < 16 * VROW; i += blockDim.x) {
-        Vhi[16 * VROW + i] = (_Float16)0.f;
+        const int row = i / VROW;
+        Vhi[16 * VROW + i] = (row == 0 || row == 4) ? (_Float16)1.0f : (_Float16)0.f;
         Vlo[16 * VROW + i] = (_Float16)0.f;
     }
 
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             s_f32x16 acc_o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
-            float m = -1e30f, lsum = 0.f;
+            float m = -1e30f;
             // S^T of key block kb_ (3 MFMAs).  With SA_SCORES_AHEAD (off by default, see the top of the file) the product of
             // block kb + 1 is issued BEFORE the softmax of block kb (16 more live registers).
 #define SA_SCORES(dst_, kb_)                                                                                        \
@@ -382,18 +386,17 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 }
                 mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
                 const float m_new = fmaxf(m, mraw * SC);
-                const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-                const float off = 10.0f - m_new;
-                float psum = 0.f;
+                // rescale only when some query of the wave saw a new maximum (after the first blocks it rarely moves): a
+                // wave-uniform branch that saves the exp2 and the 16 multiplies of the common case; alpha would be exactly 1
+                if (__any(m_new > m)) {
+                    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sc[r] = __builtin_amdgcn_exp2f(__fmaf_rn(sc[r], SC, off));
-                    psum += sc[r];
+                    for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
                 }
-                lsum = lsum * alpha + psum;
-                m = m_new;
+                const float off = 10.0f - m_new;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+                for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(__fmaf_rn(sc[r], SC, off));
+                m = m_new;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     s_f16x8 p_h, p_l;
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                     acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h, acc_o, 0, 0, 0);
                 }
             }
-            lsum += __shfl_xor(lsum, 32, 64);
-            const float inv = 1.0f / (lsum * 16.0f);           // lsum carries the x1024 of p already; v x16
+            // accumulator row 16 / 20 (register 8): sum over ALL keys of 1.0 x p x 1024 -- the denominator, complete in both halves
+            const float inv = 1.0f / (acc_o[8] * 16.0f);       // p carries x1024, v x16
 
             // ---- out-proj: av^T += W_o[:, 16 head .. 16 head + 15] . o_head^T  (one k-step; o rows = registers 0..7) ----
             s_f16x8 o_h, o_l;
