@@ -509,7 +509,18 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
             if (i < n4) {
                 const float* p = partial + base + (size_t)i * 4;
                 float4 v = *reinterpret_cast<const float4*>(p);
-                for (int k = 1; k < ksplit; ++k) {
+                int k = 1;
+                for (; k + 4 <= ksplit; k += 4) {          // four slabs in flight per round trip; the ADDS stay in slab order
+                    const float4 w0 = *reinterpret_cast<const float4*>(p + (size_t)k * slab);
+                    const float4 w1 = *reinterpret_cast<const float4*>(p + (size_t)(k + 1) * slab);
+                    const float4 w2 = *reinterpret_cast<const float4*>(p + (size_t)(k + 2) * slab);
+                    const float4 w3 = *reinterpret_cast<const float4*>(p + (size_t)(k + 3) * slab);
+                    v.x += w0.x; v.y += w0.y; v.z += w0.z; v.w += w0.w;
+                    v.x += w1.x; v.y += w1.y; v.z += w1.z; v.w += w1.w;
+                    v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
+                    v.x += w3.x; v.y += w3.y; v.z += w3.z; v.w += w3.w;
+                }
+                for (; k < ksplit; ++k) {
                     const float4 w = *reinterpret_cast<const float4*>(p + (size_t)k * slab);
                     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
                 }

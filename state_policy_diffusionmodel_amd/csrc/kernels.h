@@ -214,13 +214,13 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
                              const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s);
 
-// ---- row-wise tail of a C = 128 SelfAttention block (sa_tail.hip): out_proj + x -> LayerNorm -> ff1 -> GELU -> ff2 + av ----
+// ---- row-wise tail of a C = 128 / 256 SelfAttention block (sa_tail.hip): out_proj + x -> LayerNorm -> ff1 -> GELU -> ff2 + av ----
 bool sa_tail_supported(int C, unsigned sw);
-hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
-                             const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
-                             const float* ln_b, const float* ab, int L, hipStream_t s);
+hipError_t launch_sa_tail(int C, const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
+                          const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
+                          const float* ln_b, const float* ab, int L, hipStream_t s);
 // qkv = LayerNorm(x) W_in^T + b_in of the same blocks (LayerNorm from the row itself)
-hipError_t launch_sa_qkv128(const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
-                            const float* ln_b, const float* ab, int L, hipStream_t s);
+hipError_t launch_sa_qkv(int C, const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
+                         const float* ln_b, const float* ab, int L, hipStream_t s);
 
 }  // namespace spdm

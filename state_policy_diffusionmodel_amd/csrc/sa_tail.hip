@@ -1,4 +1,4 @@
-// sa_tail.hip -- the row-wise tail of a SelfAttention block with C = 128 channels (sa1, sa4) in ONE kernel:
+// sa_tail.hip -- the row-wise tail of a SelfAttention block with C = 128 (sa1, sa4) or C = 256 (sa2, sa3) channels in ONE kernel:
 //
 //   av  = o W_o^T + b_o + x                       (out_proj + residual,        models/Unet_FiLmLayer.py:79-80)
 //   out = GELU(LayerNorm(av) W_1^T + b_1) W_2^T + b_2 + av      (ff_self + residual,               :63-68, :81)
@@ -8,7 +8,8 @@
 // (0.4 GB), and the two intermediates live in LDS / registers.
 //
 //   * 4 waves, each a 32 x 64 accumulator tile (v_mfma_f32_16x16x32_f16, split-fp16 operands like every other
-//     contraction of the path: hi*hi + hi*lo + lo*hi into fp32);
+//     contraction of the path: hi*hi + hi*lo + lo*hi into fp32): 2 x 2 waves over 64 rows x 128 channels, or 1 x 4 over
+//     32 rows x 256 channels -- same slab bytes, same registers per thread, same tile per wave in both shapes;
 //   * the A operand of each product is a 64-row x 128-channel slab in LDS (conv_wide's row format: per 32-channel
 //     chunk [32 x fp16 hi | 32 x fp16 lo], rows padded to 144 bytes); weights come straight from global memory in
 //     fragment order (frag_order_weights, taps = 1), one 32-channel chunk ahead, also across the three products;
@@ -33,16 +34,24 @@ typedef _Float16 tf16x2 __attribute__((ext_vector_type(2)));
 constexpr float T_ACT_SCALE = 16.0f;            // operand scales of the split scheme (activations 2^4, weights 2^7)
 constexpr float T_DESCALE = 1.0f / 2048.0f;
 constexpr int T_LDK = 36;                       // floats per LDS row of one 32-channel chunk (128 + 16 pad bytes)
-constexpr int T_C = 128, T_M = 64;           // 64 token rows per workgroup: 8 row pieces per thread (av + work set = 64 registers)
+// shape of one workgroup: TM token rows x C channels = 8192 values = 8 row pieces (4 channels each) per thread
+template <int C> struct TailShape {
+    static_assert(C == 128 || C == 256, "C = 128 or 256");
+    static constexpr int TM = 8192 / C;             // 64 | 32 rows
+    static constexpr int WM = TM / 32, WN = 4 / WM; // waves along rows / channels (each 32 x 64)
+    static constexpr int NCH = C / 32;              // 32-channel chunks of a row
+    static constexpr int TPR = C / 4, RPP = 256 / TPR;   // threads per row, rows per pick-up pass
+    static constexpr int NP = TM / RPP;             // row pieces per thread (8)
+};
 
 struct SaTailArgs {
-    const float* o;        // [M][128] attention output (heads concatenated)
-    const float* x;        // [M][128] block input (residual of the out-projection)
-    float* out;            // [M][128]
+    const float* o;        // [M][C] attention output (heads concatenated)
+    const float* x;        // [M][C] block input (residual of the out-projection)
+    float* out;            // [M][C]
     int M;
-    const float *wf_o, *wf_1, *wf_2;            // fragment-order split weights (128 x 128 each)
+    const float *wf_o, *wf_1, *wf_2;            // fragment-order split weights (C x C each)
     const float *b_o, *b_1, *b_2, *ln_g, *ln_b;
-    const float* ab; int L;                     // optional [M / L][2][128]: x is y = A x + B per sample of L rows (FiLM tail folded in)
+    const float* ab; int L;                     // optional [M / L][2][C]: x is y = A x + B per sample of L rows (FiLM tail folded in)
 };
 
 __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
@@ -52,51 +61,56 @@ __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
     const tf16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
     return tf32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
-// sum over the 32 lanes of a half-wave (xor offsets < 32 stay inside the half)
-__device__ __forceinline__ float thalf_sum(float v) {
+// sum over the TPR consecutive lanes that hold one row (32: a half-wave; 64: the wave)
+template <int TPR>
+__device__ __forceinline__ float trow_sum(float v) {
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-// FiLM tail folded into the load of the block input (film_coef_kernel): piece i (rows m0 + 8 i .. + 7, columns 4 c16 ..)
-// becomes A x + B with the coefficients of its sample.  L % 8 == 0, so a piece never straddles two samples and the sample
-// index is wave-uniform; when the whole 64-row tile lies in one sample the coefficients are loaded once.
-__device__ __forceinline__ void tail_film_fold(tf32x4 (&v)[8], const float* __restrict__ ab, int L, int m0, int M, int c16) {
-    if (L % T_M == 0) {
-        const float* ab_ = ab + (size_t)(m0 / L) * 2 * T_C + c16 * 4;
-        const tf32x4 A = *reinterpret_cast<const tf32x4*>(ab_), B = *reinterpret_cast<const tf32x4*>(ab_ + T_C);
+// FiLM tail folded into the load of the block input (film_coef_kernel): piece i (row m0 + RPP i + srow0, columns 4 cq ..)
+// becomes A x + B with the coefficients of its sample; when the whole tile lies in one sample they are loaded once.
+template <int C>
+__device__ __forceinline__ void tail_film_fold(tf32x4 (&v)[8], const float* __restrict__ ab, int L, int m0, int M, int cq, int srow0) {
+    using S = TailShape<C>;
+    if (L % S::TM == 0) {
+        const float* ab_ = ab + (size_t)(m0 / L) * 2 * C + cq * 4;
+        const tf32x4 A = *reinterpret_cast<const tf32x4*>(ab_), B = *reinterpret_cast<const tf32x4*>(ab_ + C);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = v[i] * A + B;
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float* ab_ = ab + (size_t)(min(m0 + 8 * i, M - 1) / L) * 2 * T_C + c16 * 4;
-            v[i] = v[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + T_C);
+            const float* ab_ = ab + (size_t)(min(m0 + S::RPP * i + srow0, M - 1) / L) * 2 * C + cq * 4;
+            v[i] = v[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + C);
         }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) {
+template <int C>
+__global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
+    using S = TailShape<C>;
+    constexpr int T_C = C, T_M = S::TM, NCH = S::NCH, RPP = S::RPP, TPR = S::TPR;
     constexpr int RT = 2, CT = 4;                       // per wave: 32 rows x 64 columns = 2 x 4 tiles of 16 x 16
-    constexpr int NP = T_M / 8;                         // row pieces per thread
+    constexpr int NP = S::NP;                           // row pieces per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, kg = lane >> 4;
+    const int wm = wave / S::WN, wn = wave % S::WN, l16 = lane & 15, kg = lane >> 4;
     const int M = a.M;
     const int m0 = blockIdx.x * T_M;
 
-    float* Abuf = smem;                                 // [4 chunks][64 rows][T_LDK]  (36.9 KB)
-    float* otile = smem;                                // [64][128] fp32, aliases the slab between products
+    float* Abuf = smem;                                 // [NCH chunks][TM rows][T_LDK]  (36.9 KB)
+    float* otile = smem;                                // [TM][C] fp32 (32 KB), aliases the slab between products
 
-    // row-wise piece i of this thread: row 8 i + srow0, columns 4 c16 .. 4 c16 + 3
-    const int c16 = tid & 31, srow0 = tid >> 5;
+    // row-wise piece i of this thread: row RPP i + srow0, columns 4 c16 .. 4 c16 + 3
+    const int c16 = tid % TPR, srow0 = tid / TPR;
     const int aoff0 = (wm * 32 + l16) * T_LDK + kg * 4;
 
-    // B operands of 32-channel chunk kc of a 128 x 128 weight: blocks (kc 8 + nb16) x {hi, lo} of 256 floats
+    // B operands of 32-channel chunk kc of a C x C weight: blocks (kc C/16 + nb16) x {hi, lo} of 256 floats
     const size_t wlane = ((size_t)(wn * CT) * 2) * 256 + lane * 4;
-    constexpr size_t WCHUNK = (size_t)8 * 2 * 256;
+    constexpr size_t WCHUNK = (size_t)(C / 16) * 2 * 256;
     tf16x8 fb[2][CT][2], fa[2][2];
 #define TAIL_LOAD_B(slot_, w_, kc_)                                                                  \
     {                                                                                                \
@@ -112,25 +126,25 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
         fa[slot_][0] = *reinterpret_cast<const tf16x8*>(p_);                                         \
         fa[slot_][1] = *reinterpret_cast<const tf16x8*>(p_ + 16);                                    \
     }
-    // slab <- the thread's 16 row pieces v_[i] (fp32), split to fp16 hi / lo
+    // slab <- the thread's 8 row pieces v_[i] (fp32), split to fp16 hi / lo
 #define TAIL_WRITE_SLAB(v_)                                                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                             \
         const tf32x2 p0_ = tsplit2(v_[i_].x, v_[i_].y), p1_ = tsplit2(v_[i_].z, v_[i_].w);           \
-        float* rowp_ = Abuf + ((c16 >> 3) * T_M + 8 * i_ + srow0) * T_LDK;                           \
+        float* rowp_ = Abuf + ((c16 >> 3) * T_M + RPP * i_ + srow0) * T_LDK;                         \
         *reinterpret_cast<tf32x2*>(rowp_ + (c16 & 7) * 2) = tf32x2{p0_.x, p1_.x};                    \
         *reinterpret_cast<tf32x2*>(rowp_ + 16 + (c16 & 7) * 2) = tf32x2{p0_.y, p1_.y};               \
     }
-    // acc = slab . W^T over the four 32-channel chunks; the weights of `wnext_` chunk 0 are prefetched at the end
+    // acc = slab . W^T over the NCH 32-channel chunks; the weights of `wnext_` chunk 0 are prefetched at the end
 #define TAIL_GEMM(w_, wnext_)                                                                        \
     {                                                                                                \
         _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_)                                        \
             _Pragma("unroll") for (int ct_ = 0; ct_ < CT; ++ct_) acc[rt_][ct_] = tf32x4{0.f, 0.f, 0.f, 0.f}; \
         TAIL_LOAD_FA(0, 0, 0)                                                                        \
-        _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                          \
-            if (kc + 1 < 4) { TAIL_LOAD_B((kc + 1) & 1, w_, kc + 1) } else { TAIL_LOAD_B(0, wnext_, 0) } \
+        _Pragma("unroll") for (int kc = 0; kc < NCH; ++kc) {                                        \
+            if (kc + 1 < NCH) { TAIL_LOAD_B((kc + 1) & 1, w_, kc + 1) } else { TAIL_LOAD_B(0, wnext_, 0) } \
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                     \
                 if (rt + 1 < RT) { TAIL_LOAD_FA((rt + 1) & 1, kc, rt + 1) }                          \
-                else if (kc + 1 < 4) { TAIL_LOAD_FA(0, kc + 1, 0) }                                  \
+                else if (kc + 1 < NCH) { TAIL_LOAD_FA(0, kc + 1, 0) }                                \
                 __builtin_amdgcn_sched_barrier(0);                                                   \
                 _Pragma("unroll") for (int c = 0; c < CT; ++c)                                      \
                     acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[rt & 1][0], fb[kc & 1][c][0], acc[rt][c], 0, 0, 0); \
@@ -161,18 +175,18 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
     tf32x4 av[NP], v[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int row = min(m0 + 8 * i + srow0, M - 1);
+        const int row = min(m0 + RPP * i + srow0, M - 1);
         v[i] = *reinterpret_cast<const tf32x4*>(a.o + (size_t)row * T_C + c16 * 4);
-        if (m0 + 8 * i + srow0 >= M) v[i] = tf32x4{0.f, 0.f, 0.f, 0.f};
+        if (m0 + RPP * i + srow0 >= M) v[i] = tf32x4{0.f, 0.f, 0.f, 0.f};
     }
     TAIL_WRITE_SLAB(v)
     // the residual rows x are fetched now, into the registers that will hold av: in flight during the first product
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int row = min(m0 + 8 * i + srow0, M - 1);
+        const int row = min(m0 + RPP * i + srow0, M - 1);
         av[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
     }
-    if (a.ab != nullptr) tail_film_fold(av, a.ab, a.L, m0, M, c16);
+    if (a.ab != nullptr) tail_film_fold<C>(av, a.ab, a.L, m0, M, c16, srow0);
     __syncthreads();
 
     tf32x4 acc[RT][CT];
@@ -186,15 +200,15 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
         const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int r = 8 * i + srow0;
+            const int r = RPP * i + srow0;
             tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + r * T_C + c16 * 4);
             t += bo;
             t += av[i];
             av[i] = t;
-            // LayerNorm over the row's 128 values (two-pass, like torch): the row sits on this half-wave
-            const float mean = thalf_sum((t.x + t.y) + (t.z + t.w)) * (1.0f / 128.0f);
+            // LayerNorm over the row's C values (two-pass, like torch): the row sits on TPR consecutive lanes
+            const float mean = trow_sum<TPR>((t.x + t.y) + (t.z + t.w)) * (1.0f / (float)C);
             const tf32x4 d = {t.x - mean, t.y - mean, t.z - mean, t.w - mean};
-            const float var = thalf_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+            const float var = trow_sum<TPR>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / (float)C);
             const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);        // v_rsq_f32 (1 ulp)
             v[i] = tf32x4{d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w};
             __builtin_amdgcn_sched_barrier(0);          // one row piece at a time: register pressure
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
         const tf32x4 b1 = *reinterpret_cast<const tf32x4*>(a.b_1 + c16 * 4);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + (8 * i + srow0) * T_C + c16 * 4);
+            tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + (RPP * i + srow0) * T_C + c16 * 4);
             t += b1;
             v[i] = tf32x4{gelu_erf(t.x), gelu_erf(t.y), gelu_erf(t.z), gelu_erf(t.w)};
             __builtin_amdgcn_sched_barrier(0);
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
         const tf32x4 b2 = *reinterpret_cast<const tf32x4*>(a.b_2 + c16 * 4);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int r = 8 * i + srow0;
+            const int r = RPP * i + srow0;
             if (m0 + r < M) {
                 tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + r * T_C + c16 * 4);
                 t += b2;
@@ -245,29 +259,32 @@ __global__ __launch_bounds__(256, 2) void sa_tail128_kernel(const SaTailArgs a) 
 // three 128-column products (q, k, v), each stored straight from its row-wise pick-up.  As conv_gemm_kernel<1 tap>
 // this GEMM re-read the input once per 128-column tile and took its LayerNorm statistics from HBM.
 struct SaQkvArgs {
-    const float* x; float* qkv; int M;          // [M][128] -> [M][384]
-    const float* wf;                            // fragment-order split in_proj weight (384 x 128)
+    const float* x; float* qkv; int M;          // [M][C] -> [M][3 C]
+    const float* wf;                            // fragment-order split in_proj weight (3 C x C)
     const float *b_in, *ln_g, *ln_b;
     const float* ab; int L;                     // optional FiLM-tail coefficients, as in SaTailArgs
 };
 
-__global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
+template <int C>
+__global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
+    using S = TailShape<C>;
+    constexpr int T_C = C, T_M = S::TM, NCH = S::NCH, RPP = S::RPP, TPR = S::TPR;
     constexpr int RT = 2, CT = 4;
-    constexpr int NP = T_M / 8;
+    constexpr int NP = S::NP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, kg = lane >> 4;
+    const int wm = wave / S::WN, wn = wave % S::WN, l16 = lane & 15, kg = lane >> 4;
     const int M = a.M;
     const int m0 = blockIdx.x * T_M;
     float* Abuf = smem;
     float* otile = smem;
-    const int c16 = tid & 31, srow0 = tid >> 5;
+    const int c16 = tid % TPR, srow0 = tid / TPR;
     const int aoff0 = (wm * 32 + l16) * T_LDK + kg * 4;
-    // in_proj is 384 x 128: product g (q, k, v) uses rows 128 g .. -> 16-column blocks 8 g ..; chunk stride = 24 blocks
+    // in_proj is 3 C x C: product g (q, k, v) uses rows C g .. -> 16-column blocks (C / 16) g ..; chunk stride = 3 C / 16 blocks
     const size_t wlane = ((size_t)(wn * CT) * 2) * 256 + lane * 4;
-    constexpr size_t WCHUNK = (size_t)24 * 2 * 256;
-    constexpr size_t WPROD = (size_t)8 * 2 * 256;
+    constexpr size_t WCHUNK = (size_t)(3 * C / 16) * 2 * 256;
+    constexpr size_t WPROD = (size_t)(C / 16) * 2 * 256;
     tf16x8 fb[2][CT][2], fa[2][2];
     tf32x4 acc[RT][CT], v[NP];
 
@@ -277,16 +294,16 @@ __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
         const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int row = min(m0 + 8 * i + srow0, M - 1);
+            const int row = min(m0 + RPP * i + srow0, M - 1);
             v[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
         }
-        if (a.ab != nullptr) tail_film_fold(v, a.ab, a.L, m0, M, c16);
+        if (a.ab != nullptr) tail_film_fold<C>(v, a.ab, a.L, m0, M, c16, srow0);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const tf32x4 t = v[i];
-            const float mean = thalf_sum((t.x + t.y) + (t.z + t.w)) * (1.0f / 128.0f);
+            const float mean = trow_sum<TPR>((t.x + t.y) + (t.z + t.w)) * (1.0f / (float)C);
             const tf32x4 d = {t.x - mean, t.y - mean, t.z - mean, t.w - mean};
-            const float var = thalf_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+            const float var = trow_sum<TPR>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / (float)C);
             const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
             v[i] = tf32x4{d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w};
         }
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
         TAIL_GEMM(wg, wnext)
         // accumulators -> LDS: the slab must survive for the next product, so the tile goes BEHIND it
         {
-            float* ot = smem + 4 * T_M * T_LDK;
+            float* ot = smem + NCH * T_M * T_LDK;
             if (g > 0) __syncthreads();                 // every thread has picked up the previous product's rows
 #pragma unroll
             for (int rt_ = 0; rt_ < RT; ++rt_)
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
             const tf32x4 bi = *reinterpret_cast<const tf32x4*>(a.b_in + g * T_C + c16 * 4);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int r = 8 * i + srow0;
+                const int r = RPP * i + srow0;
                 if (m0 + r < M) {
                     tf32x4 t = *reinterpret_cast<const tf32x4*>(ot + r * T_C + c16 * 4);
                     t += bi;
@@ -334,30 +351,37 @@ __global__ __launch_bounds__(256, 2) void sa_qkv128_kernel(const SaQkvArgs a) {
 
 }  // namespace
 
-bool sa_tail_supported(int C, unsigned sw) { return C == T_C && !(sw & SW_NO_SA_TAIL); }
+bool sa_tail_supported(int C, unsigned sw) { return (C == 128 || C == 256) && !(sw & SW_NO_SA_TAIL); }
 
-hipError_t launch_sa_tail128(const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
-                             const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
-                             const float* ln_b, const float* ab, int L, hipStream_t s) {
-    if (rows <= 0 || (ab && (L <= 0 || L % 8 != 0)) || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
+hipError_t launch_sa_tail(int C, const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
+                          const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
+                          const float* ln_b, const float* ab, int L, hipStream_t s) {
+    if (rows <= 0 || (ab && L <= 0) || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
         return hipErrorInvalidValue;
+    if (C != 128 && C != 256) return hipErrorInvalidValue;
     SaTailArgs a{};
     a.o = o; a.x = x; a.out = out; a.M = rows;
     a.wf_o = wf_o; a.wf_1 = wf_1; a.wf_2 = wf_2;
     a.b_o = b_o; a.b_1 = b_1; a.b_2 = b_2; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
-    const size_t lds = (size_t)4 * T_M * T_LDK * sizeof(float);          // 36.9 KB
-    hipLaunchKernelGGL(sa_tail128_kernel, dim3((rows + T_M - 1) / T_M), dim3(256), lds, s, a);
+    const int TM = 8192 / C;
+    const size_t lds = (size_t)(C / 32) * TM * T_LDK * sizeof(float);          // 36.9 KB
+    if (C == 128) hipLaunchKernelGGL(sa_tail_kernel<128>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(sa_tail_kernel<256>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_sa_qkv128(const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
-                            const float* ln_b, const float* ab, int L, hipStream_t s) {
-    if (rows <= 0 || (ab && (L <= 0 || L % 8 != 0)) || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
+hipError_t launch_sa_qkv(int C, const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
+                         const float* ln_b, const float* ab, int L, hipStream_t s) {
+    if (rows <= 0 || (ab && L <= 0) || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
+    if (C != 128 && C != 256) return hipErrorInvalidValue;
     SaQkvArgs a{};
     a.x = x; a.qkv = qkv; a.M = rows; a.wf = wf_in; a.b_in = b_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
-    const size_t lds = (size_t)(4 * T_M * T_LDK + T_M * T_C) * sizeof(float);     // slab 36.9 KB + output tile 32 KB
-    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(sa_qkv128_kernel)); e != hipSuccess) return e;
-    hipLaunchKernelGGL(sa_qkv128_kernel, dim3((rows + T_M - 1) / T_M), dim3(256), lds, s, a);
+    const int TM = 8192 / C;
+    const size_t lds = (size_t)((C / 32) * TM * T_LDK + TM * C) * sizeof(float);     // slab 36.9 KB + output tile 32 KB
+    const void* kern = C == 128 ? reinterpret_cast<const void*>(sa_qkv_kernel<128>) : reinterpret_cast<const void*>(sa_qkv_kernel<256>);
+    if (hipError_t e = allow_full_lds(kern); e != hipSuccess) return e;
+    if (C == 128) hipLaunchKernelGGL(sa_qkv_kernel<128>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(sa_qkv_kernel<256>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

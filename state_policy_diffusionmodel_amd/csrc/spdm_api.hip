@@ -544,7 +544,7 @@ struct Loader {
     AttnW attn(const std::string& p, int C) {
         AttnW a;
         a.C = C;
-        if (C == 128) {
+        if (C == 128 || C == 256) {
             a.tail_wf[0] = linear_frag(p + ".attention.out_proj.weight", C, C);
             a.tail_wf[1] = linear_frag(p + ".ff_self.1.weight", C, C);
             a.tail_wf[2] = linear_frag(p + ".ff_self.3.weight", C, C);
@@ -558,7 +558,7 @@ struct Loader {
             for (int k = 0; k < 8; ++k)
                 if (!a.fw[k]) { a.fw[0] = nullptr; break; }        // the fused kernel needs all four matrices
         }
-        if (C == 128 && !(a.tail_wf[0] && a.tail_wf[1] && a.tail_wf[2])) a.tail_wf[0] = nullptr;
+        if ((C == 128 || C == 256) && !(a.tail_wf[0] && a.tail_wf[1] && a.tail_wf[2])) a.tail_wf[0] = nullptr;
         a.in_proj = linear(p + ".attention.in_proj_weight", p + ".attention.in_proj_bias", 3 * C, C, C);
         a.out_proj = linear(p + ".attention.out_proj.weight", p + ".attention.out_proj.bias", C, C, C);
         a.ln_g = vec(p + ".ln.weight", C);
@@ -887,7 +887,7 @@ struct Ctx {
         Tensor qkv = ralloc(rows, 3 * C);
         if (h->split && sa_tail_supported(C, h->sw) && (!h->weights_loaded || w.qkv_wf)) {     // LayerNorm + in_proj in one 64-row kernel (sa_tail.hip)
             if (!err && !dry)
-                check(launch_sa_qkv128(x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s), "attention in_proj");
+                check(launch_sa_qkv(C, x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s), "attention in_proj");
         } else {
             linear(x.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr, &xs, w.ln_g, w.ln_b);
         }
@@ -899,7 +899,7 @@ struct Ctx {
             // out_proj + residual + LayerNorm + ff_self + residual in one kernel (sa_tail.hip)
             Tensor out = talloc(C, level);
             if (!err && !dry)
-                check(launch_sa_tail128(att.p, x.p, out.p, rows, w.tail_wf[0], w.tail_wf[1], w.tail_wf[2], w.out_proj.b, w.ff1.b,
+                check(launch_sa_tail(C, att.p, x.p, out.p, rows, w.tail_wf[0], w.tail_wf[1], w.tail_wf[2], w.out_proj.b, w.ff1.b,
                                         w.ff2.b, w.ff_ln_g, w.ff_ln_b, abp, L, s), "attention tail");
             free(att);
             free(x);
@@ -926,7 +926,7 @@ struct Ctx {
     bool film_foldable(const AttnW& w, int level) const {
         if (!h->cfg.attention || h->arena.keep || !h->split || (h->sw & SW_NO_FILM_FOLD)) return false;
         if (sa_fused(w, level)) return HWl(level) <= 256;      // (the two-workgroup mode for longer sequences has no registers left)
-        return sa_tail_supported(w.C, h->sw) && HWl(level) % 8 == 0 && (!h->weights_loaded || (w.qkv_wf && w.tail_wf[0]));
+        return sa_tail_supported(w.C, h->sw) && (!h->weights_loaded || (w.qkv_wf && w.tail_wf[0]));
     }
     // the FiLM tail as coefficients (film_coef_kernel): returns the RAW conv tensor of v (its statistics are released),
     // *ab receives [B][2 C]
