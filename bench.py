@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 OBS_H, OBS_DIM = 10, 135
-TRAFFIC_FILE = os.path.join("profiles", "r02_roofline_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r02_roofline_traffic.json")       # rocprofv3 PMC passes of round 2 (tools/profile_sweep.sh)
 TRAFFIC_FALLBACK = os.path.join("profiles", "r01_roofline_traffic.json")
 
 

@@ -38,13 +38,19 @@ def main():
     prefix = sys.argv[3]
     json.dump({"fetch": fetch, "write": write}, open(prefix + "_hbm_traffic_pmc.json", "w"), indent=1)
     n = tot = 0.0
+    all_bytes = 0.0
     for k, (cnt, avg) in fetch.items():
+        if k in write:
+            all_bytes += cnt * (2.0 * avg + write[k][1]) * 1024.0
         if is_conv3x3(k) and k in write:
             n += cnt
             tot += cnt * (2.0 * avg + write[k][1]) * 1024.0
+    steps = max(fetch.get("out_step_kernel", [1, 0])[0], 1)        # one out_step_kernel launch per denoise step
     json.dump({
         "kernel_class": "conv3x3_wide_kernel<...> + conv_gemm_kernel<HALO=true,...> (all 3x3/3x1 implicit-GEMM launches of a denoise step)",
         "traffic_bytes_per_launch": tot / max(n, 1), "launches_profiled": int(n),
+        "hbm_bytes_per_step": all_bytes / steps, "steps_profiled": int(steps),
+        "config": {"batch": int(sys.argv[4]) if len(sys.argv) > 4 else 4096, "horizon": 32, "state_dim": 3, "kind": "ddpm", "attention": True},
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1`; "
                   "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read, "
                   "MI355X_MICROARCH.md HBM section); aggregated by tools/pmc_traffic.py; raw per-kernel averages in "

@@ -28,7 +28,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in csv.DictReader(open(os.path.join(src, "sq", "run_counter_collection.csv"))):
     k = short(r["Kernel_Name"])
-    if "conv3x3_wide" in k or "conv_gemm_kernel" in k or "sa_fused" in k:
+    if "conv3x3_wide" in k or "conv_gemm_kernel" in k or "sa_" in k or "attention" in k:
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_WAVE_CYCLES":
             cnt[k] += 1
@@ -44,6 +44,8 @@ out = {"_method": "rocprofv3 --pmc (SQ counters in one pass, GRBM_GUI_ACTIVE in 
 for k, v in acc.items():
     d = {c: v[c] / cnt[k] for c in v}
     d["launches"] = cnt[k]
+    if d.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_conflict_ratio"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
     if k in g:
         d["GRBM_GUI_ACTIVE_per_launch"] = g[k] / cnt[k]
         d["clock_GHz_from_GRBM"] = g[k] / 8 / gd[k]
