@@ -59,7 +59,8 @@ constexpr int LDK = 36;
 #ifndef WIDE_LDS_PERM
 #define WIDE_LDS_PERM 1
 #endif
-template <bool W2> struct WidePitch { static constexpr int value = (W2 || !WIDE_LDS_PERM) ? 36 : 40; };
+template <bool W2, bool PIPE = false> struct WidePitch { static constexpr int value = (W2 || PIPE || !WIDE_LDS_PERM) ? 36 : 40; };
+// (PIPE keeps two slabs: 2 x 276 rows only fit two workgroups per CU at the 144-byte pitch, and the conflict is harmless)
 #ifndef WIDE_STAGE_GROUP
 #define WIDE_STAGE_GROUP 1
 #endif
@@ -104,14 +105,17 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
     return v;
 }
 
-template <int NT, int PRO, bool W2, int RT, int WN>
+template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE>
 // launch bound (256, 2): a 256-register budget.  The 8 x 2 variants with a prologue then carry 88-128 bytes of scratch per lane
 // (stats finalisation state parked across the main loop); with (256, 1) the compiler allocates 203-250 registers and no scratch,
 // but schedules the loop worse: measured 10.5 vs 9.6-9.9 ms per step (same box, alternating).  Keep 2.
 #ifndef WIDE_MINB
 #define WIDE_MINB 2
 #endif
-__global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS) {
+#ifndef WIDE_PIPE8_MINB
+#define WIDE_PIPE8_MINB 1      // experiment: the 128-row-per-wave pipelined variants alone on a CU (512 registers, no scratch)
+#endif
+__global__ __launch_bounds__(256, (PIPE && RT == 8) ? WIDE_PIPE8_MINB : WIDE_MINB) void conv3x3_wide_kernel(const GemmArgs a, const int epi_slots, const int NS) {
     constexpr int WM = 4 / WN;                          // 4 waves: 2 x 2, or 4 x 1 for 64-wide outputs (each wave 64 rows x 64 columns)
     constexpr int CT = 2 * NT;                          // RT 16-row x CT 16-column tiles per wave (RT = 8: 128-row strip;
                                                         // RT = 4: 64 rows -- 128-row workgroup tiles for small / coarse layers)
@@ -152,9 +156,10 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     // even chunk ranges: the flat (chunk, tap) sequence of the tap-pair loop must have even length
     const int kc0 = 2 * (int)((long long)ks * (K / (2 * CK)) / ksp), kc1 = (ksp > 1) ? 2 * (int)((long long)(ks + 1) * (K / (2 * CK)) / ksp) : K / CK;
 
-    constexpr int LDK = WidePitch<W2>::value;                        // (shadows the namespace constant: every macro below uses it)
-    constexpr bool PERM = WIDE_LDS_PERM && !W2;
-    constexpr bool DB = WIDE_DB && (NT == 2) && !W2;                 // (the other loops keep the single slab)
+    static_assert(!PIPE || (NT == 2 && !W2), "the pipelined hand-over exists in the tap loop of 128-wide tiles");
+    constexpr int LDK = WidePitch<W2, PIPE>::value;                  // (shadows the namespace constant: every macro below uses it)
+    constexpr bool PERM = WIDE_LDS_PERM && !W2 && !PIPE;
+    constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);       // (the other loops keep the single slab)
     float* Abuf = smem;                       // [QZ][LDK]: the slab the MFMA loop reads
     float* Awr = smem + (DB ? QZ * LDK : 0);  // the slab being staged (DB: the idle one of two)
     float* smean = smem + (DB ? 2 : 1) * QZ * LDK;     // [NS]
@@ -336,7 +341,9 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         // slots = 64 registers), so every A fragment is read from LDS once per tap and feeds 12 MFMAs; the next
         // tap's weights are loaded a whole tap (96 MFMAs) ahead.  Loop body = two taps (compile-time slots); the
         // flat tap sequence over (chunk, tap) has even length because K % 64 == 0 (checked on the host).
-        f16x8 fbt[2][4][2], fat[2][2];
+        // PIPE with a CU to itself (512 registers): THREE weight slots, a tap's weights are loaded two taps ahead
+        constexpr bool D2 = PIPE && RT == 8 && WIDE_PIPE8_MINB == 1;
+        f16x8 fbt[D2 ? 3 : 2][4][2], fat[2][2];
 #define TAP_LOAD_B(slot_, chunk_, tap_)                                                              \
         if (!dbg_no_wload) {                                                                         \
             const float* p_ = wfl + (size_t)((tap_) * nchunks + (chunk_)) * wtap;                    \
@@ -357,6 +364,117 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         const bool t3 = (TAPS == 3);
 #define TAP_SHIFT(tap_) (t3 ? ((tap_) - 1) * W * LDK : (((tap_) / 3 - 1) * W + ((tap_) - ((tap_) / 3) * 3 - 1)) * LDK)
 #define TAP_BIT(tap_) (t3 ? 3 * (tap_) + 1 : (tap_))
+        if constexpr (PIPE) {
+            // Pipelined hand-over (3x3 kernels only: host).  Chunk-outer loop, the 9 taps unrolled, so tap, weight slot
+            // and staging pass are compile-time.  While chunk c is multiplied, the slab of chunk c + 1 is built in the
+            // idle buffer ONE 32-row pass per tap: pass t is transformed (GroupNorm affine, GELU, fp16 split) and written
+            // at tap t from a ring of three 16-byte registers loaded three taps earlier (passes 0-2 during taps 6-8 of
+            // the previous chunk) -- no hand-over stall, no 36 staging registers, ONE barrier per chunk.
+            f32x4 ar[3];
+            int pm0 = m0 - halo + srow_t, srow_p = srow_t, aoff_p = aoff0;
+            // (the per-tap addresses below are loop-invariant; hoisted out of the chunk loop they would be ~100 live registers.
+            //  Opaque copies, refreshed per chunk, make the compiler recompute them where they are used.)
+#define PIPE_OPAQUE() asm volatile("" : "+v"(pm0), "+v"(srow_p), "+v"(aoff_p));
+#define PIPE_LOAD_FA(slot_, tap_, shift_, rt_)                                                       \
+            {                                                                                        \
+                const unsigned mb_ = (am[(rt_) / 3] >> (9 * ((rt_) % 3) + (tap_))) & 1u;             \
+                const int o_ = mb_ ? aoff_p + WIDE_ROWOFF(rt_) * LDK + (shift_) : zoff;              \
+                fat[slot_][0] = *reinterpret_cast<const f16x8*>(Abuf + o_);                          \
+                fat[slot_][1] = *reinterpret_cast<const f16x8*>(Abuf + o_ + 16);                     \
+            }
+#define PIPE_LOAD(slot_, chunk_, pass_)                                                              \
+            {                                                                                        \
+                const int mc_ = min(max(pm0 + (pass_) * RP, 0), M - 1);                              \
+                ar[slot_] = *reinterpret_cast<const f32x4*>(abase + (size_t)mc_ * a.src_ld + (chunk_) * CK); \
+            }
+#define PIPE_GB(chunk_)                                                                              \
+            if (pro) {                                                                               \
+                g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + (chunk_) * CK + c4 * 4);         \
+                b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (chunk_) * CK + c4 * 4);          \
+            }
+#define PIPE_STAGE(slot_, pass_)                                                                     \
+            {                                                                                        \
+                f32x4 v_ = ar[slot_];                                                                \
+                if (pro) {                                                                           \
+                    const int bi_ = (int)((abidx >> (BB * (pass_))) & ((1ull << BB) - 1));           \
+                    const float rs_ = srstd[bi_], mu_ = smean[bi_];                                  \
+                    v_.x = (v_.x - mu_) * (rs_ * g4r.x) + b4r.x;                                     \
+                    v_.y = (v_.y - mu_) * (rs_ * g4r.y) + b4r.y;                                     \
+                    v_.z = (v_.z - mu_) * (rs_ * g4r.z) + b4r.z;                                     \
+                    v_.w = (v_.w - mu_) * (rs_ * g4r.w) + b4r.w;                                     \
+                    if (pro_gelu) {                                                                  \
+                        v_.x = gelu_erf(v_.x); v_.y = gelu_erf(v_.y);                                \
+                        v_.z = gelu_erf(v_.z); v_.w = gelu_erf(v_.w);                                \
+                    }                                                                                \
+                }                                                                                    \
+                if (!((avalid >> (pass_)) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                     \
+                const f32x2 p0_ = split2(v_.x, v_.y), p1_ = split2(v_.z, v_.w);                      \
+                float* row_ = Awr + min((pass_) * RP + srow_p, QA + 1) * LDK;                        \
+                *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{p0_.x, p1_.x};                      \
+                *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{p0_.y, p1_.y};                 \
+            }
+#define PIPE_SHIFT(t_) ((((t_) / 3 - 1) * W + ((t_) % 3 - 1)) * LDK)
+            TAP_LOAD_B(0, kc0, 0)
+            if (D2) { TAP_LOAD_B(1, kc0, 1) }
+            WIDE_LOAD_A(kc0)
+            WIDE_STAGE_A()
+            __syncthreads();
+            { float* t_ = Abuf; Abuf = Awr; Awr = t_; }
+            {
+                const int c1 = min(kc0 + 1, kc1 - 1);
+                PIPE_LOAD(0, c1, 0)
+                PIPE_LOAD(1, c1, 1)
+                PIPE_LOAD(2, c1, 2)
+                PIPE_GB(c1)
+            }
+            WIDE_STAMP(2)
+            PIPE_LOAD_FA(0, 0, PIPE_SHIFT(0), 0)
+            for (int chunk = kc0; chunk < kc1; ++chunk) {
+                const int cn1 = min(chunk + 1, kc1 - 1), cn2 = min(chunk + 2, kc1 - 1);     // (past the end: harmless re-reads)
+                PIPE_OPAQUE()
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (D2) {
+                        if (t < 7) { TAP_LOAD_B((t + 2) % 3, chunk, t + 2) } else { TAP_LOAD_B((t + 2) % 3, cn1, t - 7) }
+                    } else {
+                        if (t < 8) { TAP_LOAD_B((t + 1) & 1, chunk, t + 1) } else { TAP_LOAD_B(1, cn1, 0) }
+                    }
+                    if (t < APASS) { PIPE_STAGE(t % 3, t) }
+                    if (t + 3 < APASS) { PIPE_LOAD(t % 3, cn1, t + 3) }
+                    else if (t >= 6) { PIPE_LOAD(t - 6, cn2, t - 6) }
+                    if (t == 8) { PIPE_GB(cn2) }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (rt + 1 < RT) { PIPE_LOAD_FA((rt + 1) & 1, t, PIPE_SHIFT(t), rt + 1) }
+                        else if (t < 8) { PIPE_LOAD_FA(0, t + 1, PIPE_SHIFT(t + 1), 0) }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][0], fbt[D2 ? t % 3 : (t & 1)][c][0], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][0], fbt[D2 ? t % 3 : (t & 1)][c][1], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][1], fbt[D2 ? t % 3 : (t & 1)][c][0], acc[rt][c], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __syncthreads();            // every wave is done with this chunk's slab; the next one is complete
+                { float* t_ = Abuf; Abuf = Awr; Awr = t_; }
+                if (!D2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { fbt[0][c][0] = fbt[1][c][0]; fbt[0][c][1] = fbt[1][c][1]; }    // tap 0's weights sit in slot 1 (9 is odd)
+                }
+                PIPE_LOAD_FA(0, 0, PIPE_SHIFT(0), 0)
+            }
+#undef PIPE_OPAQUE
+#undef PIPE_LOAD_FA
+#undef PIPE_LOAD
+#undef PIPE_GB
+#undef PIPE_STAGE
+#undef PIPE_SHIFT
+        } else {
         const int ntaps = (kc1 - kc0) * TAPS;
         TAP_LOAD_B(0, kc0, 0)
         WIDE_LOAD_A(kc0)
@@ -409,6 +527,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
                 chunk = nchunk;
             }
         }
+        }   // !PIPE
 #undef TAP_LOAD_B
 #undef TAP_LOAD_FA
 #undef TAP_SHIFT
@@ -670,7 +789,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef WIDE_ROWOFF
 }
 
-template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2>
+template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = (4 / WN) * RT * 16, N_T = WN * 32 * NT, NTHR = 256;
     constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 9) ? 128 : (APASS <= 10) ? 64 : 32;
@@ -678,12 +797,13 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     const int QA = M_T + 2 * halo;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
-    constexpr bool DB = WIDE_DB && (NT == 2) && !W2;
-    constexpr int LDK = WidePitch<W2>::value;
+    constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);
+    constexpr int LDK = WidePitch<W2, PIPE>::value;
+    if (PIPE && a.taps != 9) return hipErrorInvalidValue;
     size_t lds = (size_t)((DB ? 2 : 1) * (QA + 2) * LDK + 2 * NS) * sizeof(float);
     lds = std::max(lds, (size_t)((M_T / (W2 ? 2 : WIDE_NH)) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN>;
+    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     if (a.ksplit > 1 && a.K % 64 != 0) return hipErrorInvalidValue;          // split-K walks even chunk ranges
@@ -719,6 +839,11 @@ bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
 
 hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     if (!conv_wide_supported(a, g)) return hipErrorInvalidValue;
+    // Pipelined slab hand-over (PIPE: the next chunk's slab is staged one 32-row pass per tap into a second buffer, one barrier
+    // per chunk).  Measured per layer at B = 512 and 4096 (tools/bench_convs.py, SPDM_NO_WIDE_PIPE on / off): a win only on the
+    // 64-wide 64-row-per-wave variant with >= 8 chunks (up2.dc2a 249 -> 218 us); neutral on 128 x 128 tiles; a loss where a
+    // workgroup has few chunks (inc.b 330 -> 363) or 128 rows per wave (register spills, see below).  So: only there.
+    const bool pipe = a.taps == 9 && a.K >= 256 && !(a.sw & SW_NO_WIDE_PIPE);
     if (g.m_tile == 128) {
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4>(a, g, s);
@@ -730,6 +855,9 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
         return launch_wide_cfg<2, PRO_GN_GELU, true>(a, g, s);
     }
     if (g.n_tile == 128) {
+        // (not for the 128-row-per-wave variants: at 256 registers the pipelined loop spills -- 965 vs 931 us on up3.dc1a,
+        //  1301 vs 999 with the GELU prologue -- and alone on a CU with 512 registers, even with a third weight slot loaded
+        //  two taps ahead, it is 10 % slower than two workgroups of the old loop: profiles/r02_conv_ablation.txt)
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN>(a, g, s);
         return launch_wide_cfg<2, PRO_GN_GELU>(a, g, s);
@@ -737,6 +865,11 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
     // 64-wide outputs: four waves along M, each 64 rows x all 64 columns (an A fragment feeds 12 MFMAs, as on 128-wide
     // tiles), tap-pair loop; K % 64 != 0 keeps the 2 x 2 arrangement with 128 x 32 waves
     if (a.K % 64 == 0 && !(a.sw & SW_WIDE_N64_2X2)) {
+        if (pipe) {
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 1, true>(a, g, s);
+            if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 1, true>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 1, true>(a, g, s);
+        }
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 1>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 1>(a, g, s);
         return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 1>(a, g, s);

@@ -65,6 +65,29 @@ def test_wide_conv_kernel_shapes_against_exact_fp32_path():
         # 128-row tiles (4 waves x 64 x 64): small batches / coarse levels, and the 3-tap convs of the W == 1 level
         (110, 32, 8, 64, 128, 9, 2, 0), (437, 16, 4, 128, 128, 9, 0, 0), (1600, 8, 2, 128, 128, 9, 1, 0),
         (4000, 4, 1, 256, 256, 3, 2, 0), (4093, 4, 1, 512, 256, 3, 1, 0), (7000, 4, 1, 256, 512, 3, 1, 0), (4096, 4, 1, 512, 512, 3, 0, 0),
+        # 64-wide outputs with K >= 256: the pipelined slab hand-over (two buffers, one staging pass per tap), three prologues,
+        # ragged last tile, several samples per tile, an odd number of chunk pairs
+        (1024, 16, 4, 256, 64, 9, 1, 0), (777, 16, 4, 256, 64, 9, 2, 0), (300, 32, 8, 256, 64, 9, 0, 0), (1100, 8, 4, 320, 64, 9, 2, 0),
+    ]
+    for B, H, W, Cin, Cout, taps, pro, epi in cases:
+        ms = (ctypes.c_double * 3)()
+        _lib.check(lib.spdm_bench_gemm(0, B, H, W, Cin, Cout, taps, pro, epi, 1, 1, 0, ms), "spdm_bench_gemm")
+        assert 0.0 <= ms[1] <= 5e-5, ((B, H, W, Cin, Cout, taps, pro, epi), ms[1])
+        assert 0.0 <= ms[2] <= 1e-5, ((B, H, W, Cin, Cout, taps, pro, epi), "GroupNorm totals", ms[2])
+
+
+def test_split_k_launches_against_exact_fp32_path():
+    """Small grids: split-K conv launches + the fixed-order combine kernel (outputs and GroupNorm totals) against the exact
+    fp32 kernel -- batch 1..64 at every level, 3x3 and 3x1, width-2 maps on the 256-row zero-tap-skipping tiles, a sample
+    length that is not a power of two, and determinism (two launches, identical bits, checked through the model in
+    test_batch_independence_and_determinism)."""
+    from state_policy_diffusionmodel_amd import _lib
+    lib = _lib.load()
+    cases = [  # B, H, W, Cin, Cout, taps, pro, epi
+        (1, 32, 8, 128, 128, 9, 0, 0), (1, 16, 4, 256, 256, 9, 2, 0), (1, 8, 2, 512, 512, 9, 2, 0), (1, 4, 1, 512, 512, 3, 1, 0),
+        (3, 4, 1, 256, 512, 3, 0, 0), (8, 8, 2, 512, 128, 9, 1, 0), (64, 4, 1, 512, 256, 3, 2, 0), (37, 16, 4, 128, 64, 9, 2, 0),
+        (256, 8, 2, 512, 512, 9, 0, 0), (512, 8, 2, 512, 512, 9, 2, 0), (512, 4, 1, 512, 512, 3, 2, 0), (2, 24, 8, 64, 128, 9, 1, 0),
+        (5, 3, 1, 256, 256, 3, 2, 0),
     ]
     for B, H, W, Cin, Cout, taps, pro, epi in cases:
         ms = (ctypes.c_double * 3)()
