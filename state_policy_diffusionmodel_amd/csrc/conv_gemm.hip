@@ -687,6 +687,16 @@ int spdm_tune(int idx, int dflt) {
 
 GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, bool stats_epi) {
     GemmGeom g;
+    g.skinny = 0;
+    if (stats_epi && taps != 1 && conv_skinny_geometry(M, N, K, HW, W, taps, split, sw, &g.m_tile, &g.n_tile)) {
+        g.skinny = 1;
+        g.ksplit = 1;
+        g.n_tiles = N / g.n_tile;
+        g.st_m_tile = g.m_tile;
+        g.st_n_tiles = g.n_tiles;
+        g.slots = stats_slots(HW, g.st_m_tile, g.st_n_tiles);
+        return g;
+    }
     const int nt128 = (N % 128 == 0) ? N / 128 : 0;
     const int nt_pref = nt128 ? nt128 : N / 64;
     bool big = split && taps != 1 && M >= 256;
@@ -792,6 +802,7 @@ hipError_t launch_gemm(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.ksplit = 1;
     const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    if (g.skinny) return launch_conv_skinny(a, g, s);
     if (g.ksplit > 1) {
         if ((size_t)g.ksplit * a.M * a.N * sizeof(float) > SPLITK_WORKSPACE_BYTES || a.dst_ld != a.N) return hipErrorInvalidValue;
         a.ksplit = g.ksplit;

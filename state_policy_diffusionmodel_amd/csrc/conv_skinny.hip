@@ -1,0 +1,321 @@
+// conv_skinny.hip -- 3x3 / 3x1 convolution for a handful of rows (the closed-loop caller: run_predictions.py:140-175 calls
+// sample() at batch 1, so the coarse levels have M = B H_l W_l = 16 or 4 rows against K = 9 Cin up to 4608).
+//
+// Same math, operand formats and epilogue contract as conv_wide.hip / conv_gemm.hip (split-fp16 operands, hi*hi + hi*lo + lo*hi
+// into fp32, GroupNorm(1,C) -> GELU prologue applied at staging, GroupNorm partial sums as the epilogue; replaces
+// nn.Conv2d(k=3, padding=1, bias=False) + the GroupNorm/GELU around it, models/Unet_FiLmLayer.py:101-115).  What such a launch
+// is bound by is how fast its weights (up to 9.4 MB) stream into the chip, through how many wave fronts -- the matrix
+// work is nothing.  So the shape is the opposite of the big-batch kernels:
+//
+//   * one workgroup = 8 waves = one (<= 64 rows) x (64 | 32 columns) output tile over the WHOLE K range;
+//   * the input slab of ALL chunks (rows + halo, every 32-channel chunk, prologue applied once) is staged in LDS up
+//     front -- it is tiny (<= 87 KB);
+//   * the 8 waves split K: wave w takes the (chunk, tap) items i = w, w + 8, ... and streams their weight fragments
+//     straight from global memory in fragment order (frag_order_weights, kernels.h), one item ahead; every wave
+//     accumulates the whole tile;
+//   * the 8 partial tiles are added through LDS in the fixed order w = 0..7 (deterministic, no atomics) and the epilogue --
+//     output rows, per-sample fp64 GroupNorm partial sums -- runs in the same kernel: no partial slabs in HBM, no combine
+//     launch (the split-K path of the larger kernels pays ~10 us per layer for those at this size).
+#include <algorithm>
+
+#include "device_utils.h"
+
+namespace spdm {
+
+namespace {
+
+typedef float k_f32x4 __attribute__((ext_vector_type(4)));
+typedef float k_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 k_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 k_f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float K_ACT_SCALE = 16.0f;          // the split scheme's operand scales (2^4 activations, 2^7 weights)
+constexpr float K_DESCALE = 1.0f / 2048.0f;
+constexpr int K_CK = 32, K_LDK = 36;          // channels per chunk; floats per slab row (128 + 16 pad bytes)
+constexpr int K_WAVES = 8, K_NTHR = 512;
+
+__device__ __forceinline__ k_f32x2 ksplit2(float a, float b) {
+    const float xa = a * K_ACT_SCALE, xb = b * K_ACT_SCALE;
+    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
+    const k_f16x2 h = {ha, hb};
+    const k_f16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    return k_f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
+}
+
+// RT row tiles of 16 (M_T = 16 RT), CT column tiles of 16 (N_T = 16 CT)
+template <int RT, int CT, int PRO>
+__global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a, const int epi_slots, const int NS) {
+    constexpr int M_T = RT * 16, N_T = CT * 16;
+    constexpr bool pro = (PRO != PRO_NONE), pro_gelu = (PRO == PRO_GN_GELU);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int HW = a.HW, W = a.W, H = a.H, M = a.M, K = a.K, N = a.N, taps = a.taps;
+    const int halo = W + 1;
+    const int QA = M_T + 2 * halo;            // slab rows of one chunk; row QA is all zero (what a masked tap reads)
+    const int QZ = QA + 1;
+    const int nch = K / K_CK;
+    const int n_ntiles = N / N_T;
+    const int mtile = blockIdx.x / n_ntiles, ntile = blockIdx.x - mtile * n_ntiles;
+    const int m0 = mtile * M_T, n0 = ntile * N_T;
+
+    float* Abuf = smem;                                   // [nch][QZ][K_LDK]
+    float* smean = Abuf + (size_t)nch * QZ * K_LDK;       // [NS]
+    float* srstd = smean + NS;                            // [NS]
+
+    // ---- statistics of the samples the slab touches ----
+    int bh_first = 0;
+    if (pro) {
+        const int lo = max(m0 - halo, 0), hi = min(m0 + M_T + halo, M) - 1;
+        bh_first = lo / HW;
+        const int bh_last = hi / HW;
+        for (int t = tid; t <= bh_last - bh_first; t += K_NTHR) {
+            float mean, rstd;
+            sample_mean_rstd(a.pro_stats, bh_first + t, mean, rstd);
+            smean[t] = mean;
+            srstd[t] = rstd;
+        }
+    }
+    for (int t = tid; t < nch * K_LDK; t += K_NTHR) Abuf[((t / K_LDK) * QZ + QA) * K_LDK + t % K_LDK] = 0.f;
+    if (pro) __syncthreads();
+
+    // ---- stage the whole slab: piece p = (chunk, row q, 16-byte part c4); 8 pieces in flight per thread ----
+    {
+        const int npiece = nch * QA * 8;
+        for (int p0 = 0; p0 < npiece; p0 += K_NTHR * 8) {
+            k_f32x4 v[8];
+            int qs[8], cs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = min(p0 + j * K_NTHR + tid, npiece - 1);
+                const int c4 = p & 7, rq = p >> 3;
+                const int q = rq % QA, ch = rq / QA;
+                const int m = min(max(m0 - halo + q, 0), M - 1);
+                qs[j] = q; cs[j] = ch * 8 + c4;
+                v[j] = *reinterpret_cast<const k_f32x4*>(a.src + (size_t)m * a.src_ld + ch * K_CK + c4 * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (p0 + j * K_NTHR + tid < npiece) {
+                    const int q = qs[j], ch = cs[j] >> 3, c4 = cs[j] & 7;
+                    const int m = m0 - halo + q;
+                    k_f32x4 x = v[j];
+                    if (pro) {
+                        const int bi = min(max(m, 0), M - 1) / HW - bh_first;
+                        const float rs = srstd[bi], mu = smean[bi];
+                        const k_f32x4 g4 = *reinterpret_cast<const k_f32x4*>(a.pro_gamma + ch * K_CK + c4 * 4);
+                        const k_f32x4 b4 = *reinterpret_cast<const k_f32x4*>(a.pro_beta + ch * K_CK + c4 * 4);
+                        x.x = (x.x - mu) * (rs * g4.x) + b4.x;
+                        x.y = (x.y - mu) * (rs * g4.y) + b4.y;
+                        x.z = (x.z - mu) * (rs * g4.z) + b4.z;
+                        x.w = (x.w - mu) * (rs * g4.w) + b4.w;
+                        if (pro_gelu) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+                    }
+                    if (m < 0 || m >= M) x = k_f32x4{0.f, 0.f, 0.f, 0.f};
+                    const k_f32x2 p0_ = ksplit2(x.x, x.y), p1_ = ksplit2(x.z, x.w);
+                    float* row = Abuf + ((size_t)ch * QZ + q) * K_LDK;
+                    *reinterpret_cast<k_f32x2*>(row + c4 * 2) = k_f32x2{p0_.x, p1_.x};        // hi
+                    *reinterpret_cast<k_f32x2*>(row + 16 + c4 * 2) = k_f32x2{p0_.y, p1_.y};   // lo
+                }
+            }
+        }
+    }
+
+    // ---- per-lane A rows and tap-validity masks (bit t of am[rt]: tap t of this lane's row in row tile rt is inside the image) ----
+    unsigned am[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int m = m0 + rt * 16 + l16;
+        unsigned mask = 0u;
+        if (m < M) {
+            const int p = m % HW;
+            const int h = p / W, w = p - h * W;
+            for (int t = 0; t < taps; ++t) {
+                const int dh = (taps == 9) ? t / 3 - 1 : t - 1;
+                const int dw = (taps == 9) ? t % 3 - 1 : 0;
+                const bool ok = (h + dh >= 0) && (h + dh < H) && (w + dw >= 0) && (w + dw < W);
+                mask |= (ok ? 1u : 0u) << t;
+            }
+        }
+        am[rt] = mask;
+    }
+    const int aoff0 = (l16 + halo) * K_LDK + kg * 4;
+    const int zoff = QA * K_LDK + kg * 4;
+    // B operands: fragment-order weights, block ((tap nch + chunk) N/16 + nb16) x {hi, lo} of 256 floats
+    const float* wfl = a.wgt_frag + ((size_t)(n0 >> 4) * 2) * 256 + lane * 4;
+    const size_t wtap = (size_t)(N >> 4) * 2 * 256;          // floats per (tap, chunk)
+
+    k_f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = k_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                                          // slab complete
+
+    // ---- this wave's items: i = wave, wave + 8, ... over (chunk, tap), chunk-major ----
+    const int nitem = nch * taps;
+    k_f16x8 fb[2][CT][2];
+#define SKINNY_LOAD_B(slot_, item_)                                                                  \
+    {                                                                                                \
+        const int it_ = min((item_), nitem - 1);                                                     \
+        const int ch_ = it_ / taps, tp_ = it_ - ch_ * taps;                                          \
+        const float* p_ = wfl + (size_t)(tp_ * nch + ch_) * wtap;                                    \
+        _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_) {                                         \
+            fb[slot_][c_][0] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512);                     \
+            fb[slot_][c_][1] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512 + 256);               \
+        }                                                                                            \
+    }
+    SKINNY_LOAD_B(0, wave)
+    int slot = 0;
+    for (int item = wave; item < nitem; item += 2 * K_WAVES) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int it = item + half * K_WAVES;
+            SKINNY_LOAD_B(1 - half, it + K_WAVES)              // unconditional prefetch (clamped past the end)
+            if (it < nitem) {
+                const int ch = it / taps, tp = it - ch * taps;
+                const int dh = (taps == 9) ? tp / 3 - 1 : tp - 1;
+                const int dw = (taps == 9) ? tp - (tp / 3) * 3 - 1 : 0;
+                const float* Ab = Abuf + (size_t)ch * QZ * K_LDK;
+                const int shift = (dh * W + dw) * K_LDK;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int o = ((am[rt] >> tp) & 1u) ? aoff0 + rt * 16 * K_LDK + shift : zoff;
+                    const k_f16x8 a_h = *reinterpret_cast<const k_f16x8*>(Ab + o);
+                    const k_f16x8 a_l = *reinterpret_cast<const k_f16x8*>(Ab + o + 16);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, fb[half][c][0], acc[rt][c], 0, 0, 0);
+                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, fb[half][c][1], acc[rt][c], 0, 0, 0);
+                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, fb[half][c][0], acc[rt][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#undef SKINNY_LOAD_B
+    (void)slot;
+
+    // ---- cross-wave reduction in the fixed order w = 0..7 (the slab is dead) ----
+    __syncthreads();
+    float* red = smem;                                        // [8 waves][M_T][N_T] fp32
+    // accumulator layout: lane (l16, kg), register j of tile (rt, ct) = row 16 rt + 4 kg + j, column 16 ct + l16
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                red[((size_t)wave * M_T + rt * 16 + 4 * kg + j) * N_T + ct * 16 + l16] = acc[rt][ct][j];
+    __syncthreads();
+
+    // thread -> (row, 4 columns); M_T * N_T / 4 pieces over 512 threads
+    constexpr int NPIECE = M_T * N_T / 4;
+    float* srow = red + (size_t)K_WAVES * M_T * N_T;          // [M_T][N_T / 4][2] fp32 partials of the final values
+    for (int p = tid; p < NPIECE; p += K_NTHR) {
+        const int r = p / (N_T / 4), c4 = p - r * (N_T / 4);
+        k_f32x4 s = *reinterpret_cast<const k_f32x4*>(red + (size_t)r * N_T + c4 * 4);
+#pragma unroll
+        for (int w = 1; w < K_WAVES; ++w) s += *reinterpret_cast<const k_f32x4*>(red + ((size_t)w * M_T + r) * N_T + c4 * 4);
+        s *= K_DESCALE;
+        const int row = m0 + r;
+        if (row < M) *reinterpret_cast<k_f32x4*>(a.dst + (size_t)row * a.dst_ld + n0 + c4 * 4) = s;
+        srow[(r * (N_T / 4) + c4) * 2] = (s.x + s.y) + (s.z + s.w);
+        srow[(r * (N_T / 4) + c4) * 2 + 1] = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+    }
+    __syncthreads();
+    // per-sample totals, fixed order, fp64: one thread per sample the tile touches
+    {
+        const int t_lo = m0, t_hi = min(m0 + M_T, M);
+        if (t_hi > t_lo) {
+            const int b_first = t_lo / HW, b_last = (t_hi - 1) / HW;
+            for (int t = tid; t <= b_last - b_first; t += K_NTHR) {
+                const int b = b_first + t;
+                const int r_lo = max(b * HW, t_lo) - m0, r_hi = min((b + 1) * HW, t_hi) - m0;
+                double s1 = 0.0, s2 = 0.0;
+                for (int r = r_lo; r < r_hi; ++r)
+                    for (int c4 = 0; c4 < N_T / 4; ++c4) {
+                        s1 += (double)srow[(r * (N_T / 4) + c4) * 2];
+                        s2 += (double)srow[(r * (N_T / 4) + c4) * 2 + 1];
+                    }
+                const int slot2 = (mtile - (b * HW) / M_T) * n_ntiles + ntile;
+                double* o = a.epi_stats + ((size_t)b * epi_slots + slot2) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
+        }
+    }
+}
+
+template <int RT, int CT>
+hipError_t launch_skinny_rc(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
+    constexpr int M_T = RT * 16, N_T = CT * 16;
+    if (g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
+    const int halo = a.W + 1;
+    const int QA = M_T + 2 * halo;
+    const int nch = a.K / K_CK;
+    const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
+    size_t lds = ((size_t)nch * (QA + 1) * K_LDK + 2 * NS) * sizeof(float);
+    lds = std::max(lds, ((size_t)K_WAVES * M_T * N_T + (size_t)M_T * (N_T / 4) * 2) * sizeof(float));
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int grid = ((a.M + M_T - 1) / M_T) * (a.N / N_T);
+    const void* kern = nullptr;
+#define SKINNY_GO(PRO_)                                                                              \
+    {                                                                                                \
+        auto k_ = conv_skinny_kernel<RT, CT, PRO_>;                                                  \
+        kern = reinterpret_cast<const void*>(k_);                                                    \
+        if (hipError_t e = allow_full_lds(kern); e != hipSuccess) return e;                          \
+        hipLaunchKernelGGL(k_, dim3(grid), dim3(K_NTHR), lds, s, a, g.slots, NS);                    \
+    }
+    if (a.pro == PRO_NONE) SKINNY_GO(PRO_NONE)
+    else if (a.pro == PRO_GN) SKINNY_GO(PRO_GN)
+    else SKINNY_GO(PRO_GN_GELU)
+#undef SKINNY_GO
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// LDS bytes of the up-front slab for a tile of m_tile rows
+static size_t skinny_slab_bytes(int m_tile, int W, int K) {
+    return (size_t)(K / K_CK) * (m_tile + 2 * (W + 1) + 1) * K_LDK * sizeof(float);
+}
+
+// Shape rule (host): which launches run here, and their tile.  Returns false when the launch belongs to the other kernels.
+bool conv_skinny_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, int* m_tile, int* n_tile) {
+    // Measured per layer at batch 1-8 (tools/bench_convs.py, SPDM_NO_SKINNY on / off; profiles/r02_skinny_vs_splitk.txt): this kernel
+    // wins for <= 32 rows (6.5-10 us against 9-13.5 us for split-K launch + combine) and LOSES for 64-256 rows (17-26 against
+    // 12-16: one m-tile x N / 32 workgroups is too few wave fronts for the slab staging and the weight stream), so: M <= 32.
+    if (!split || (sw & SW_NO_SKINNY) || M > 32 || M <= 0 || K % K_CK != 0 || N % 64 != 0 || W < 1 || W > 8) return false;
+    if (!(taps == 9 || (taps == 3 && W == 1)) || M % HW != 0) return false;
+    int mt = M >= 64 ? 64 : M > 16 ? 32 : 16;
+    while (mt > 16 && skinny_slab_bytes(mt, W, K) > (size_t)96 * 1024) mt >>= 1;
+    if (skinny_slab_bytes(mt, W, K) > (size_t)150 * 1024) return false;
+    const int mtiles = (M + mt - 1) / mt;
+    // 32-wide tiles when 64-wide ones would leave the grid under 32 workgroups (more wave fronts on the weight stream)
+    const int nt = (mtiles * (N / 64) < 32) ? 32 : 64;
+    *m_tile = mt;
+    *n_tile = nt;
+    return true;
+}
+
+hipError_t launch_conv_skinny(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
+    if (!a.split || a.wgt_frag == nullptr || a.epi != EPI_STATS || a.epi_stats == nullptr || a.row_stats != nullptr || a.ksplit > 1)
+        return hipErrorInvalidValue;
+    if (a.M % a.HW != 0 || a.K % K_CK != 0 || a.N % g.n_tile != 0 || a.dst_ld % 4 != 0 || a.src_ld % 4 != 0) return hipErrorInvalidValue;
+    if (a.pro != PRO_NONE && (a.pro_stats.p == nullptr || a.pro_gamma == nullptr || a.pro_beta == nullptr)) return hipErrorInvalidValue;
+    if (g.n_tile == 64) {
+        if (g.m_tile == 64) return launch_skinny_rc<4, 4>(a, g, s);
+        if (g.m_tile == 32) return launch_skinny_rc<2, 4>(a, g, s);
+        if (g.m_tile == 16) return launch_skinny_rc<1, 4>(a, g, s);
+    } else if (g.n_tile == 32) {
+        if (g.m_tile == 64) return launch_skinny_rc<4, 2>(a, g, s);
+        if (g.m_tile == 32) return launch_skinny_rc<2, 2>(a, g, s);
+        if (g.m_tile == 16) return launch_skinny_rc<1, 2>(a, g, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace spdm

@@ -745,8 +745,9 @@ struct Ctx {
         const int slots = stats_slots(HW, m_tile, n_tiles);
         // reserve for the finest tiling any batch size can select (gemm_geometry is batch-dependent, the
         // dry run that sizes the arena is not): 128-row x 64-wide tiles, or the split-K combine kernel's row groups
-        const int slots_max = std::max(std::max(slots, stats_slots(HW, 128, std::max(1, C / 64))),   // (coarser tilings need fewer)
-                                       stats_slots(HW, combine_rows(HW, C), 1));
+        const int slots_max = std::max(std::max(std::max(slots, stats_slots(HW, 128, std::max(1, C / 64))),   // (coarser tilings need fewer)
+                                                stats_slots(HW, combine_rows(HW, C), 1)),
+                                       stats_slots(HW, 16, std::max(1, C / 32)));                      // conv_skinny's finest tiling
         size_t off = 0;
         if (!h->arena.alloc(sizeof(double) * 2 * (size_t)B * slots_max, &off)) {
             if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
