@@ -74,14 +74,18 @@ constexpr int CK = 32;    // channels per K chunk
 constexpr int LDK = 36;   // padded LDS row length (floats)
 enum { PREC_F32 = 0, PREC_SPLIT = 1 };
 
-template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI, bool W2>
+// DEEP (small grids: 4-wave split configurations with TPI = 3): the global loads of an iteration are issued TWO iterations
+// ahead into a second set of staging registers, and the A slab is double-buffered in LDS, so that a workgroup alone on its
+// CU (which is what a small grid is) is no longer paced by one weight round trip per iteration.
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI, bool W2, bool DEEP>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a, const int epi_slots) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int RP = NTHR / 8;                                     // slab rows staged per pass
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32;
     constexpr int APASS = HALO ? (M_T + 18 + RP - 1) / RP : M_T / RP;   // halo <= 9 rows each side (W <= 8)
     constexpr int WPASS = N_T / RP;                                  // per tap
-    constexpr int NBA = (TPI == 1) ? 2 : 1;                          // A slab buffers
+    constexpr int NBA = (TPI == 1 || DEEP) ? 2 : 1;                  // A slab buffers
+    static_assert(!DEEP || (NTHR == 256 && TPI == 3 && PREC == PREC_SPLIT && HALO && !W2), "DEEP: the 4-wave small-grid configurations");
     constexpr bool PP = (NTHR == 512);                               // ping-pong schedule (see main loop)
     // WDMA (experiment, OFF): weight slabs global -> LDS by LDS-DMA (global_load_lds_dwordx4; un-padded rows,
     // XOR swizzle of the 16-byte chunk with (row>>1)&7 on the per-lane source address and on the fragment
@@ -233,16 +237,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     // arrays end up in scratch -- both defeat the overlap of the loads with the MFMA block.
     f32x4 areg[APASS], wreg[WDMA ? 1 : TPI * WPASS];
     f32x4 g4r = {1.f, 1.f, 1.f, 1.f}, b4r = {0.f, 0.f, 0.f, 0.f};   // GroupNorm gain / offset of this thread's 4 channels
+    f32x4 areg2[DEEP ? APASS : 1], wreg2[DEEP ? TPI * WPASS : 1];    // DEEP: the second staging set
+    f32x4 g4r2 = {1.f, 1.f, 1.f, 1.f}, b4r2 = {0.f, 0.f, 0.f, 0.f};
 
-#define SPDM_LOAD_A(chunk_)                                                                         \
+#define SPDM_LOAD_A_X(AR_, G_, B_, chunk_)                                                          \
     {                                                                                               \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_)                                       \
-            areg[p_] = *reinterpret_cast<const f32x4*>(aptr[p_] + (kc0 + (chunk_)) * CK);           \
+            AR_[p_] = *reinterpret_cast<const f32x4*>(aptr[p_] + (kc0 + (chunk_)) * CK);            \
         if (pro) {                                                                                  \
-            g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + (kc0 + (chunk_)) * CK + c4 * 4);    \
-            b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (kc0 + (chunk_)) * CK + c4 * 4);     \
+            G_ = *reinterpret_cast<const f32x4*>(a.pro_gamma + (kc0 + (chunk_)) * CK + c4 * 4);     \
+            B_ = *reinterpret_cast<const f32x4*>(a.pro_beta + (kc0 + (chunk_)) * CK + c4 * 4);      \
         }                                                                                           \
     }
+#define SPDM_LOAD_A(chunk_) SPDM_LOAD_A_X(areg, g4r, b4r, chunk_)
     const int gw = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, provably uniform
     // per-lane part of the DMA source address: row (lane>>3) of the 8-row block, swizzled 16-byte chunk.  The
     // swizzle key (row>>1)&7 of row = 8 blk + (lane>>3) is (4 (blk&1) + (lane>>4)) & 7, and blk&1 == gw&1 for
@@ -262,34 +269,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                 (__attribute__((address_space(3))) void*)(dst_), 16, 0, 0);                         \
         }                                                                                           \
     }
-#define SPDM_LOAD_W(chunk_, tg_)                                                                    \
+#define SPDM_LOAD_W_X(WR_, chunk_, tg_)                                                             \
     if (!WDMA) {                                                                                    \
         _Pragma("unroll") for (int tp_ = 0; tp_ < TPI; ++tp_) {                                    \
             const float* wb_ = wptr + (size_t)((tg_) * TPI + tp_) * N * K + (kc0 + (chunk_)) * CK;  \
             _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                   \
-                wreg[tp_ * WPASS + p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * RP * K); \
+                WR_[tp_ * WPASS + p_] = *reinterpret_cast<const f32x4*>(wb_ + (size_t)p_ * RP * K); \
         }                                                                                           \
     }
-#define SPDM_STORE_W(buf_)                                                                          \
+#define SPDM_LOAD_W(chunk_, tg_) SPDM_LOAD_W_X(wreg, chunk_, tg_)
+#define SPDM_STORE_W_X(WR_, buf_)                                                                   \
     if (!WDMA) {                                                                                    \
         float* wd_ = Wbuf + (buf_) * TPI * N_T * LDK + srow_t * LDK + c4 * 4;                       \
         _Pragma("unroll") for (int tp_ = 0; tp_ < TPI; ++tp_)                                      \
             _Pragma("unroll") for (int p_ = 0; p_ < WPASS; ++p_)                                   \
-                *reinterpret_cast<f32x4*>(wd_ + (tp_ * N_T + p_ * RP) * LDK) = wreg[tp_ * WPASS + p_]; \
+                *reinterpret_cast<f32x4*>(wd_ + (tp_ * N_T + p_ * RP) * LDK) = WR_[tp_ * WPASS + p_]; \
     }
+#define SPDM_STORE_W(buf_) SPDM_STORE_W_X(wreg, buf_)
     // fp32 slab row: 32 floats.  split slab row: [32 x fp16 hi | 32 x fp16 lo] (same 128 bytes).
     // TRANSFORM turns the raw loaded values into what the slab holds (in the same registers; the split
     // form packs {hi0..3} into .xy and {lo0..3} into .zw); WRITE_A puts them into LDS.
-#define SPDM_TRANSFORM_A()                                                                          \
+#define SPDM_TRANSFORM_A_X(AR_, G_, B_)                                                             \
     {                                                                                               \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                     \
-            f32x4 v_ = areg[p_];                                                                    \
+            f32x4 v_ = AR_[p_];                                                                     \
             if (pro) {                                                                              \
                 const float rs_ = arstd[p_], mu_ = amean[p_];                                       \
-                v_.x = (v_.x - mu_) * (rs_ * g4r.x) + b4r.x;                                        \
-                v_.y = (v_.y - mu_) * (rs_ * g4r.y) + b4r.y;                                        \
-                v_.z = (v_.z - mu_) * (rs_ * g4r.z) + b4r.z;                                        \
-                v_.w = (v_.w - mu_) * (rs_ * g4r.w) + b4r.w;                                        \
+                v_.x = (v_.x - mu_) * (rs_ * G_.x) + B_.x;                                          \
+                v_.y = (v_.y - mu_) * (rs_ * G_.y) + B_.y;                                          \
+                v_.z = (v_.z - mu_) * (rs_ * G_.z) + B_.z;                                          \
+                v_.w = (v_.w - mu_) * (rs_ * G_.w) + B_.w;                                          \
                 if (pro_gelu) {                                                                     \
                     v_.x = gelu_erf(v_.x); v_.y = gelu_erf(v_.y);                                   \
                     v_.z = gelu_erf(v_.z); v_.w = gelu_erf(v_.w);                                   \
@@ -300,20 +309,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                 const f32x2 p0_ = split_pair(v_.x, v_.y), p1_ = split_pair(v_.z, v_.w);             \
                 v_ = f32x4{p0_.x, p1_.x, p0_.y, p1_.y};                                             \
             }                                                                                       \
-            areg[p_] = v_;                                                                          \
+            AR_[p_] = v_;                                                                           \
         }                                                                                           \
     }
-#define SPDM_WRITE_A(buf_)                                                                          \
+#define SPDM_TRANSFORM_A() SPDM_TRANSFORM_A_X(areg, g4r, b4r)
+#define SPDM_WRITE_A(buf_) SPDM_WRITE_A_X(areg, buf_)
+#define SPDM_WRITE_A_X(AR_, buf_)                                                                   \
     {                                                                                               \
         float* ad_ = Abuf + (buf_) * QZ * LDK;                                                      \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                     \
             if (p_ * RP + srow_t < QA) {                                                            \
                 float* row_ = ad_ + (p_ * RP + srow_t) * LDK;                                       \
                 if (PREC == PREC_SPLIT) {   /* hi: 8 bytes at c4*8, lo: 8 bytes at 64 + c4*8 */     \
-                    *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{areg[p_].x, areg[p_].y};       \
-                    *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{areg[p_].z, areg[p_].w};  \
+                    *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{AR_[p_].x, AR_[p_].y};         \
+                    *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{AR_[p_].z, AR_[p_].w};    \
                 } else {                                                                            \
-                    *reinterpret_cast<f32x4*>(row_ + c4 * 4) = areg[p_];                            \
+                    *reinterpret_cast<f32x4*>(row_ + c4 * 4) = AR_[p_];                             \
                 }                                                                                   \
             }                                                                                       \
         }                                                                                           \
@@ -432,7 +443,54 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 #else
     constexpr bool PP_COMPILED = false;      // product build: no second loop body, no extra register pressure
 #endif
-    if (PP_COMPILED && (dbg & DBG_PP)) {
+    if constexpr (DEEP) {
+        // iteration j = (chunk j / ngroups, tap group j % ngroups).  Data of iteration j + 2 is loaded during iteration j into
+        // staging set j & 1; data of iteration j + 1 (loaded during j - 1, set (j + 1) & 1) goes to LDS after the MFMA block
+        // of j: W -> buffer (j + 1) & 1, and -- when j + 1 opens a chunk -- the A slab -> buffer chunk & 1 (both were last
+        // read two barriers ago).  One barrier per iteration.  The prologue above staged iteration 0 from set 0.
+        {   // data of iteration 1 -> set 1
+            const int j1 = min(1, niter - 1);
+            const int c1 = j1 / ngroups, t1 = j1 - c1 * ngroups;
+            if (t1 == 0) SPDM_LOAD_A_X(areg2, g4r2, b4r2, c1)
+            SPDM_LOAD_W_X(wreg2, c1, t1)
+        }
+        int c_cur = 0, t_cur = 0;                       // (chunk, tap group) of iteration j
+        for (int it = 0; it < niter; it += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int j = it + half;
+                if (j < niter) {
+                    int t_n1 = t_cur + 1, c_n1 = c_cur;
+                    if (t_n1 == ngroups) { t_n1 = 0; c_n1 = c_cur + 1; }
+                    int t_n2 = t_n1 + 1, c_n2 = c_n1;
+                    if (t_n2 == ngroups) { t_n2 = 0; c_n2 = c_n1 + 1; }
+                    const bool have1 = (j + 1 < niter), have2 = (j + 2 < niter);
+                    // loads of iteration j + 2 (past the end: the last iteration's data again, never stored)
+                    const int cl = have2 ? c_n2 : c_cur, tl = have2 ? t_n2 : t_cur;
+                    if (half == 0) {
+                        if (have2 && t_n2 == 0) SPDM_LOAD_A_X(areg, g4r, b4r, cl)
+                        SPDM_LOAD_W_X(wreg, cl, tl)
+                    } else {
+                        if (have2 && t_n2 == 0) SPDM_LOAD_A_X(areg2, g4r2, b4r2, cl)
+                        SPDM_LOAD_W_X(wreg2, cl, tl)
+                    }
+                    SPDM_MFMA_BLOCK(c_cur, t_cur, j & 1)
+                    if (have1) {
+                        if (half == 0) {
+                            SPDM_STORE_W_X(wreg2, (j + 1) & 1)
+                            if (t_n1 == 0) { SPDM_TRANSFORM_A_X(areg2, g4r2, b4r2) SPDM_WRITE_A_X(areg2, c_n1 & 1) }
+                        } else {
+                            SPDM_STORE_W_X(wreg, (j + 1) & 1)
+                            if (t_n1 == 0) { SPDM_TRANSFORM_A_X(areg, g4r, b4r) SPDM_WRITE_A_X(areg, c_n1 & 1) }
+                        }
+                    }
+                    __syncthreads();
+                    t_cur = t_n1;
+                    c_cur = c_n1;
+                }
+            }
+        }
+    } else if (PP_COMPILED && (dbg & DBG_PP)) {
         // Ping-pong schedule (measured SLOWER than the plain schedule on MI355X; kept for experiments:
         // enable with DBG_PP) (8 waves): waves 0-3 (one per SIMD) and waves 4-7 alternate between
         // "run the MFMA block" and "stage the next slabs" (LDS writes of W, GroupNorm/GELU/split
@@ -507,6 +565,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
         }
     }
 #undef SPDM_MFMA_BLOCK
+#undef SPDM_LOAD_A_X
+#undef SPDM_LOAD_W_X
+#undef SPDM_STORE_W_X
+#undef SPDM_TRANSFORM_A_X
+#undef SPDM_WRITE_A_X
 #undef SPDM_DMA_W
 #undef SPDM_WOFF
 #undef SPDM_LOAD_A
@@ -772,10 +835,10 @@ double gemm_flops(const GemmArgs& a) {
     return 2.0 * (double)a.M * (double)a.N * (double)a.K * taps;
 }
 
-template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI, bool W2 = false>
+template <bool HALO, int PREC, int WM, int WN, int MT, int NT, int TPI, bool W2 = false, bool DEEP = false>
 static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = WM * MT * 32, N_T = WN * NT * 32, NTHR = WM * WN * 64;
-    constexpr int NBA = (TPI == 1) ? 2 : 1;
+    constexpr int NBA = (TPI == 1 || DEEP) ? 2 : 1;
     const int halo = HALO ? a.W + 1 : 0;
     const int QA = M_T + 2 * halo;
     const int NSP = (QA + 4) & ~3;
@@ -788,7 +851,7 @@ static hipError_t launch_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s
     size_t lds = (size_t)(NBA * (QA + 1) * LDK + 2 * TPI * N_T * WROW + 2 * NSP) * sizeof(float);
     lds = std::max(lds, (size_t)(M_T * WN * 2 + M_T * N_T) * sizeof(float));     // epilogue staging: srow + output tile
     if (lds > 160 * 1024 || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
-    auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI, W2>;
+    auto kern = conv_gemm_kernel<HALO, PREC, WM, WN, MT, NT, TPI, W2, DEEP>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     const int grid = n_mtiles * g.n_tiles * std::max(a.ksplit, 1);
@@ -846,6 +909,12 @@ static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipSt
         // iteration (3 x the bytes in flight per round trip)
         const long long wgs = (long long)((a.M + 127) / 128) * g.n_tiles;
         if (wgs <= 512 && !(a.sw & SW_NO_SMALL_TPI3)) {
+            // DEEP (loads two iterations ahead, double-buffered A slab) is an opt-in experiment (SPDM_DEEP=1): measured over all
+            // 31 layers at B = 1 / 256 / 512 it changes NOTHING (369 vs 364, 1018 vs 1014, 1440 vs 1441 us of convs per step) --
+            // these launches are not paced by their weight round trips but by the serial phases of a workgroup that is alone on
+            // its CU: ~1150 MFMA cycles + ~1600 cycles of GroupNorm/GELU/split staging + LDS writes and fragment reads per iteration.
+            // (64-wide tiles only: with 128-wide tiles two staging sets do not fit 256 registers.)
+            if ((a.sw & SW_DEEP) && g.n_tile == 64) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 3, false, true>(a, g, s);
             if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2, 3>(a, g, s);
             return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 3>(a, g, s);
         }

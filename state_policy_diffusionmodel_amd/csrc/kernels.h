@@ -56,7 +56,7 @@ enum : unsigned {
     SW_NO_WIDE = 1u << 0, SW_NO_WIDE128 = 1u << 1, SW_NO_W2 = 1u << 2, SW_NO_T512 = 1u << 3, SW_T512 = 1u << 4,
     SW_T3_BIG = 1u << 5, SW_NO_SMALL_TPI3 = 1u << 6, SW_WIDE_N64_2X2 = 1u << 7, SW_NO_SA_FUSED = 1u << 8,
     SW_NO_SA_TAIL = 1u << 9, SW_ATTN_VALU = 1u << 10, SW_SA_NO_WLDS = 1u << 11, SW_NO_FILM_FOLD = 1u << 12,
-    SW_NO_GRAPH = 1u << 13, SW_NO_SPLITK = 1u << 14, SW_ARENA_TRACE = 1u << 15, SW_NO_WIDE_PIPE = 1u << 16, SW_NO_SKINNY = 1u << 17,
+    SW_NO_GRAPH = 1u << 13, SW_NO_SPLITK = 1u << 14, SW_ARENA_TRACE = 1u << 15, SW_NO_WIDE_PIPE = 1u << 16, SW_NO_SKINNY = 1u << 17, SW_DEEP = 1u << 18,
 };
 struct SwitchName { const char* env; unsigned bit; };
 inline const SwitchName* switch_table(int* n) {
@@ -65,7 +65,7 @@ inline const SwitchName* switch_table(int* n) {
         {"SPDM_T512", SW_T512}, {"SPDM_T3_BIG", SW_T3_BIG}, {"SPDM_NO_SMALL_TPI3", SW_NO_SMALL_TPI3},
         {"SPDM_WIDE_N64_2X2", SW_WIDE_N64_2X2}, {"SPDM_NO_SA_FUSED", SW_NO_SA_FUSED}, {"SPDM_NO_SA_TAIL", SW_NO_SA_TAIL},
         {"SPDM_ATTN_VALU", SW_ATTN_VALU}, {"SPDM_SA_NO_WLDS", SW_SA_NO_WLDS}, {"SPDM_NO_FILM_FOLD", SW_NO_FILM_FOLD},
-        {"SPDM_NO_GRAPH", SW_NO_GRAPH}, {"SPDM_NO_SPLITK", SW_NO_SPLITK}, {"SPDM_ARENA_TRACE", SW_ARENA_TRACE}, {"SPDM_NO_WIDE_PIPE", SW_NO_WIDE_PIPE}, {"SPDM_NO_SKINNY", SW_NO_SKINNY}};
+        {"SPDM_NO_GRAPH", SW_NO_GRAPH}, {"SPDM_NO_SPLITK", SW_NO_SPLITK}, {"SPDM_ARENA_TRACE", SW_ARENA_TRACE}, {"SPDM_NO_WIDE_PIPE", SW_NO_WIDE_PIPE}, {"SPDM_NO_SKINNY", SW_NO_SKINNY}, {"SPDM_DEEP", SW_DEEP}};
     *n = (int)(sizeof(t) / sizeof(t[0]));
     return t;
 }
