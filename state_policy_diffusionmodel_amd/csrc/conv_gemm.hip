@@ -55,7 +55,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 //              The fp16 matrix pipe runs 16x the fp32 one per clock, so 3 MFMAs per K=16 are 5.3x the
 //              fp32-MFMA rate.  Weights are split once at load time (host); activations at LDS-staging.
 constexpr float SPLIT_ACT_SCALE = 16.0f;      // 2^4
-constexpr float SPLIT_WGT_SCALE = 128.0f;     // 2^7   (host side: spdm_api.hip upload_split)
+// (weights: 2^7, applied on the host -- spdm_api.hip upload_split)
 constexpr float SPLIT_DESCALE = 1.0f / 2048.0f;
 
 // {packed fp16 hi(a,b), packed fp16 lo(a,b)} of the pre-scaled pair, as raw bits in two floats.

@@ -34,7 +34,7 @@ typedef float s_f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 s_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 s_f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SA_C = 64, SA_D = 16, SA_HEADS = 4;
+constexpr int SA_C = 64;          // 4 heads of d = 16
 // 1: issue the S product of key block kb + 1 before the softmax of block kb (software pipelining inside the wave).
 // Measured 9.32 vs 9.28 ms per step without it (three alternating runs): the partner wave on the SIMD already covers
 // the softmax with its own MFMAs, so the default stays 0.
