@@ -13,13 +13,24 @@ namespace spdm {
 // inc.first: Conv2d(1, 64, 3, padding=1, bias=False) on pad_to(x, 8)
 // (models/Unet_FiLmLayer.py:286,288 -> :101,111).  One workgroup per trajectory; the padded
 // (Hp, Wp) image sits in LDS; thread = (row lane, 4 output channels).  Also emits the
-// GroupNorm partial sums of its output (one slot per sample).
+// GroupNorm partial sums of its output (one slot per row part of a sample: gridDim.y parts, so that a batch of one is
+// not a single workgroup).  Being the first kernel of a denoise step it also does the loop bookkeeping of
+// advance_kernel (adv: -2 none, -1 step <- step + 1, >= 0 step <- adv): nothing that runs beside it reads those words.
+struct StepAdvance { int* step_dev; int* t_dev; const int* timesteps; int n_steps; int adv; };
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ dst, double* __restrict__ stats,
-                                                      int slots, int H0, int D, int Hp, int Wp, int lh, int lw) {
+                                                      int slots, int H0, int D, int Hp, int Wp, int lh, int lw,
+                                                      const StepAdvance sa) {
     extern __shared__ __attribute__((aligned(16))) float sx[];   // [Hp*Wp] + 8 floats reduction scratch
     const int b = blockIdx.x, tid = threadIdx.x;
     const int HW = Hp * Wp;
+    if (sa.adv >= -1 && b == 0 && blockIdx.y == 0 && tid == 0) {
+        const int i = (sa.adv >= 0) ? sa.adv : (*sa.step_dev + 1);
+        *sa.step_dev = i;
+        *sa.t_dev = sa.timesteps[min(max(i, 0), sa.n_steps - 1)];
+    }
+    const int rows_part = HW / (int)gridDim.y;             // rows of this part (host: gridDim.y divides HW / 16... see launch)
+    const int r_begin = blockIdx.y * rows_part, r_end = r_begin + rows_part;
     for (int i = tid; i < HW; i += 256) {
         const int h = i / Wp, c = i - h * Wp;
         const int h0 = h - lh, d = c - lw;
@@ -31,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + t * 64 + c4 * 4);
     float s1 = 0.f, s2 = 0.f;
-    for (int r = rl; r < HW; r += 16) {
+    for (int r = r_begin + rl; r < r_end; r += 16) {
         const int h = r / Wp, c = r - h * Wp;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -55,18 +66,25 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     if (tid == 0) {
         double a1 = 0.0, a2 = 0.0;
         for (int i = 0; i < 4; ++i) { a1 += (double)red[2 * i]; a2 += (double)red[2 * i + 1]; }
-        stats[(size_t)b * slots * 2] = a1;
-        stats[(size_t)b * slots * 2 + 1] = a2;
+        stats[((size_t)b * slots + blockIdx.y) * 2] = a1;             // slot of row part blockIdx.y (m_tile = rows_part, n_tiles = 1)
+        stats[((size_t)b * slots + blockIdx.y) * 2 + 1] = a2;
     }
 }
 
+// row parts per sample: 4 (Hp is a multiple of 8, so HW / 4 is a multiple of 16 rows) -- StatsRef{m_tile = HW / 4, n_tiles = 1}
+int conv_in_parts(int Hp, int Wp) { return ((Hp * Wp) % 64 == 0) ? 4 : 1; }
+
 hipError_t launch_conv_in(const float* x, const float* w, float* dst, double* stats, int B, int H0, int D,
-                          int Hp, int Wp, int lh, int lw, hipStream_t s) {
+                          int Hp, int Wp, int lh, int lw, int* step_dev, int* t_dev, const int* timesteps, int n_steps,
+                          int adv, hipStream_t s) {
     const int HW = Hp * Wp;
     const size_t lds = (size_t)(HW + 8) * sizeof(float);
     if (lds > 64 * 1024 || B <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_in_kernel, dim3(B), dim3(256), lds, s, x, w, dst, stats, stats_slots(HW, HW, 1), H0, D,
-                       Hp, Wp, lh, lw);
+    if (adv >= -1 && (!step_dev || !t_dev || !timesteps || n_steps < 1)) return hipErrorInvalidValue;
+    const int parts = conv_in_parts(Hp, Wp);
+    const StepAdvance sa{step_dev, t_dev, timesteps, n_steps, adv};
+    hipLaunchKernelGGL(conv_in_kernel, dim3(B, parts), dim3(256), lds, s, x, w, dst, stats, stats_slots(HW, HW / parts, 1), H0, D,
+                       Hp, Wp, lh, lw, sa);
     return hipGetLastError();
 }
 

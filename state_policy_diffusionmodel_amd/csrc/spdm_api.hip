@@ -952,6 +952,7 @@ struct Ctx {
         return y;
     }
     int h_tcount = 1;
+    int adv = -2;          // loop bookkeeping done by conv_in_kernel: -2 none, -1 advance, >= 0 set
 };
 
 // one U-Net evaluation on h->d_x... : x (B,H0,D) -> feat (B, Hp*Wp, 64)
@@ -961,11 +962,11 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
     // ---- inc = DoubleConvolution(1, 64) on the zero-padded trajectory (:286-288) ----
     Value v0;
     v0.t = c.talloc(64, 0);
-    v0.st = c.salloc(c.HWl(0), 64, c.HWl(0), 1);
+    v0.st = c.salloc(c.HWl(0), 64, c.HWl(0) / conv_in_parts(h->Hp, h->Wp), 1);
     v0.gamma = h->inc.gamma; v0.beta = h->inc.beta;
     if (!c.err && !c.dry)
         c.check(launch_conv_in(x, h->w_inc_first, v0.t.p, v0.st.p, B, h->cfg.horizon, h->cfg.state_dim, h->Hp, h->Wp,
-                               h->lh, h->lw, c.s), "conv_in");
+                               h->lh, h->lw, h->d_step, h->d_t, h->d_timesteps, h->n_steps, c.adv, c.s), "conv_in");
     Value x1 = c.conv(v0, h->inc.second, 0, /*gelu=*/true, h->inc.gamma, h->inc.beta);   // x1 = GN(raw), pending
     c.free(v0);
     if (h->arena.keep) {
@@ -1187,10 +1188,9 @@ extern "C" int spdm_sample_begin(spdm_handle* h, int32_t B, const float* d_cond,
 // one denoise iteration on stream s: loop bookkeeping (explicit index i >= 0, or "advance by one" for i < 0 --
 // the form a captured graph replays), U-Net, fused 1x1 conv + scheduler update + inpainting
 static int enqueue_step(spdm_handle* h, int i, hipStream_t s) {
-    if (i >= 0) HIP_TRY(launch_set_step(h->d_step, h->d_t, h->d_timesteps, h->n_steps, i, s));
-    else HIP_TRY(launch_advance(h->d_step, h->d_t, h->d_timesteps, h->n_steps, s));
     Ctx c{h, h->sB, s, false};
     c.h_tcount = 1;
+    c.adv = (i >= 0) ? i : -1;          // the step's first kernel (conv_in_kernel) does the bookkeeping
     h->arena.reset();
     Tensor feat;
     SPDM_TRY(plan_unet(c, h->d_x, h->have_film, &feat));
