@@ -17,11 +17,10 @@ m.sample({k: v.clone() for k, v in obs.items()}, x_T=x_T.clone(), batched=True, 
 m.noise_steps = 1000
 res = {}
 for mode in ("graph", "plain"):
-    if mode == "plain": os.environ["SPDM_NO_GRAPH"] = "1"
-    else: os.environ.pop("SPDM_NO_GRAPH", None)
+    m._engine.set_switch("SPDM_NO_GRAPH", mode == "plain")      # (the environment is read once, at engine creation)
     torch.cuda.synchronize(); t0 = time.time()
     out = m.sample({k: v.clone() for k, v in obs.items()}, x_T=x_T.clone(), batched=True, seed=5)
     torch.cuda.synchronize(); el = time.time() - t0
     res[mode] = out.cpu()
-    print(mode, "1000-step DDPM, B=256, H=32, D=3:", round(el, 3), "s =", round(el, 3), "ms/step", "finite", bool(torch.isfinite(out).all()), "absmax", float(out.abs().max()))
+    print(mode, "1000-step DDPM, B=256, H=32, D=3:", round(el, 3), "s =", round(el, 3), "ms/step", "nonfinite flag", m._engine.nonfinite(), "finite", bool(torch.isfinite(out).all()), "absmax", float(out.abs().max()))
 print("graph == plain bit for bit:", torch.equal(res["graph"], res["plain"]))
