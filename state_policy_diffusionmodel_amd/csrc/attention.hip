@@ -94,10 +94,103 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// Short sequences with a wide head (L <= 16 tokens, d = 32 / 64: sa2, sa3, sa4).  attention_kernel gives every query one
+// thread, i.e. L threads per (sample, head) pair, and a pair's K / V rows cost 2 L (d + 4) floats of LDS: at L = 16, d = 64
+// that is 8.7 KB for 16 threads -- 4-5 waves per CU, and the kernel crawled at ~2 TB/s on latency.  Here DS = 4 lanes share a
+// query, each owning d / 4 of its features (partial dot products, two xor-shuffles per key): 4 x the threads on the same
+// LDS bytes.  The softmax arithmetic per query is the same sequence of operations as in attention_kernel.
+template <int D, int DS>
+__global__ __launch_bounds__(256) void attention_ds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           int L, int C, int heads, int G, int GS, int npairs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // per pair: K [L][D + 4], V [L][D + 4]
+    constexpr int RS = D + 4, D4 = D / 4, DP = D / DS, DP4 = DP / 4;
+    static_assert(DS == 4 && DP % 4 == 0, "4 lanes per query");
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const size_t ld = (size_t)3 * C;
+    const int pair0 = blockIdx.x * G;
+    float* Ksm = sm;
+    float* Vsm = sm + (size_t)G * GS;
+    for (int i = tid; i < G * L * D4; i += nthr) {
+        const int g = i / (L * D4), r = i - g * (L * D4);
+        const int j = r / D4, k4 = r - j * D4;
+        const int bh = min(pair0 + g, npairs - 1), b = bh / heads, hd = bh - b * heads;
+        const float* base = qkv + (size_t)b * L * ld + hd * D;
+        *reinterpret_cast<float4*>(Ksm + g * GS + j * RS + k4 * 4) = *reinterpret_cast<const float4*>(base + j * ld + C + k4 * 4);
+        *reinterpret_cast<float4*>(Vsm + g * GS + j * RS + k4 * 4) = *reinterpret_cast<const float4*>(base + j * ld + 2 * C + k4 * 4);
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)D);
+    // thread -> (pair g, query qi, feature slice ds): DS consecutive lanes share a query
+    const int ds = tid & (DS - 1), qg = tid / DS;
+    const int g = qg / L, qi = qg - g * L;
+    const int bh = pair0 + g;
+    const bool live = (g < G) && (bh < npairs);
+    const int bhc = live ? bh : min(pair0, npairs - 1);
+    const int gc = live ? g : 0, qc = live ? qi : 0;
+    const int b = bhc / heads, hd = bhc - b * heads;
+    const float* base = qkv + (size_t)b * L * ld + hd * D + ds * DP;
+    const float* Ks = Ksm + gc * GS + ds * DP;
+    const float* Vs = Vsm + gc * GS + ds * DP;
+    float q[DP], o[DP];
+#pragma unroll
+    for (int k4 = 0; k4 < DP4; ++k4) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)qc * ld + k4 * 4);
+        q[4 * k4] = v.x * scale; q[4 * k4 + 1] = v.y * scale; q[4 * k4 + 2] = v.z * scale; q[4 * k4 + 3] = v.w * scale;
+    }
+#pragma unroll
+    for (int k = 0; k < DP; ++k) o[k] = 0.f;
+    float m = -1e30f, l = 0.f;
+    for (int j = 0; j < L; ++j) {
+        const float* kr = Ks + j * RS;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < DP; k += 4) {
+            const float4 kv = *reinterpret_cast<const float4*>(kr + k);
+            s0 += q[k] * kv.x; s1 += q[k + 1] * kv.y; s2 += q[k + 2] * kv.z; s3 += q[k + 3] * kv.w;
+        }
+        float sc = (s0 + s1) + (s2 + s3);
+        sc += __shfl_xor(sc, 1, 64);              // the four feature slices of this query (fixed order: deterministic)
+        sc += __shfl_xor(sc, 2, 64);
+        const float mn = fmaxf(m, sc);
+        const float alpha = att_exp_neg(m - mn);
+        const float p = att_exp_neg(sc - mn);
+        l = l * alpha + p;
+        const float* vr = Vs + j * RS;
+#pragma unroll
+        for (int k = 0; k < DP; k += 4) {
+            const float4 vv = *reinterpret_cast<const float4*>(vr + k);
+            o[k] = o[k] * alpha + p * vv.x; o[k + 1] = o[k + 1] * alpha + p * vv.y;
+            o[k + 2] = o[k + 2] * alpha + p * vv.z; o[k + 3] = o[k + 3] * alpha + p * vv.w;
+        }
+        m = mn;
+    }
+    if (live) {
+        const float inv = 1.0f / l;
+        float* orow = out + ((size_t)b * L + qi) * C + hd * D + ds * DP;
+#pragma unroll
+        for (int k4 = 0; k4 < DP4; ++k4)
+            *reinterpret_cast<float4*>(orow + k4 * 4) =
+                make_float4(o[4 * k4] * inv, o[4 * k4 + 1] * inv, o[4 * k4 + 2] * inv, o[4 * k4 + 3] * inv);
+    }
+}
+
 hipError_t launch_attention(const float* qkv, float* out, int B, int L, int C, int heads, hipStream_t s) {
     if (B <= 0 || L <= 0 || heads <= 0 || C % heads != 0) return hipErrorInvalidValue;
     const int d = C / heads;
     const int npairs = B * heads;
+    if (L <= 16 && (L & (L - 1)) == 0 && (d == 32 || d == 64)) {
+        // four lanes per query: G pairs per 256-thread workgroup, G L 4 = 256
+        const int G = 64 / L;
+        const int RS = d + 4;
+        const int GS = L * RS + ((4 - (L * RS) % 64 + 64) % 64);
+        const size_t lds = (size_t)2 * G * GS * sizeof(float);
+        if (lds <= 64 * 1024) {
+            const dim3 grid((npairs + G - 1) / G), block(256);
+            if (d == 64) hipLaunchKernelGGL((attention_ds_kernel<64, 4>), grid, block, lds, s, qkv, out, L, C, heads, G, GS, npairs);
+            else hipLaunchKernelGGL((attention_ds_kernel<32, 4>), grid, block, lds, s, qkv, out, L, C, heads, G, GS, npairs);
+            return hipGetLastError();
+        }
+    }
     const int G = (L <= 32 && (L & (L - 1)) == 0) ? 64 / L : 1;          // (sample, head) pairs per workgroup
     const int RS = d + 4;
     const int GS = L * RS + ((4 - (L * RS) % 64 + 64) % 64);               // group stride = 4 (mod 64 banks)

@@ -5,7 +5,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "advance_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "conv_in_kernel" in r["Kernel_Name"]]      # first kernel of a denoise step
 step = rows[idx[-1]:]
 end = next((i for i, r in enumerate(step) if "out_step" in r["Kernel_Name"]), len(step) - 1)
 step = step[: end + 1]
