@@ -763,7 +763,10 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
     const int nt128 = (N % 128 == 0) ? N / 128 : 0;
     const int nt_pref = nt128 ? nt128 : N / 64;
     bool big = split && taps != 1 && M >= 256;
-    if (big && (long long)((M + 255) / 256) * nt_pref < 192) big = false;
+    // 128-wide layers: a 256-row tiling of <= 256 workgroups (at most one per CU) loses to twice as many 128-row tiles, two per
+    // CU (up2.dc1 at B = 512: 115 -> 103, 127 -> 114 us; down1.dc2 at B = 1024: 42 -> 36, 72 -> 63); 64-wide layers do not
+    // (down1.dc1 at 1024: 25 -> 28): tools/bench_convs.py with SPDM_TUNE4
+    if (big && (long long)((M + 255) / 256) * nt_pref < spdm_tune(4, nt128 ? 257 : 192)) big = false;
     // 3-tap convs (W == 1 level): 128-row tiles (conv_wide's 4 x (64 x 64) variant, two workgroups per CU) until the
     // 256-row tiling would give every CU two workgroups
     if (big && taps == 3 && HW % 4 == 0 && (long long)((M + 255) / 256) * nt_pref < 512 && !(sw & SW_T3_BIG)) big = false;
@@ -791,7 +794,8 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
         while (S > 1 && (size_t)S * M * N * sizeof(float) > SPLITK_WORKSPACE_BYTES) --S;
         if (t256 * S >= target * 3 / 4 && S <= spdm_tune(3, 4)) {
             g.m_tile = 256; g.n_tile = nt128 ? 128 : 64; g.n_tiles = N / g.n_tile; g.ksplit = S;
-            g.st_m_tile = combine_rows(HW, N); g.st_n_tiles = 1;
+            if (S > 1) { g.st_m_tile = combine_rows(HW, N); g.st_n_tiles = 1; }      // the combine kernel writes the statistics
+            else { g.st_m_tile = g.m_tile; g.st_n_tiles = g.n_tiles; }               // (S == 1: the plain 256-row launch)
             g.slots = stats_slots(HW, g.st_m_tile, g.st_n_tiles);
             return g;
         }

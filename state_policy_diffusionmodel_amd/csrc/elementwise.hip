@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
 }
 
-// row parts per sample: 4 (Hp is a multiple of 8, so HW / 4 is a multiple of 16 rows) -- StatsRef{m_tile = HW / 4, n_tiles = 1}
-int conv_in_parts(int Hp, int Wp) { return ((Hp * Wp) % 64 == 0) ? 4 : 1; }
+// row parts per sample: 4 at small batch (Hp is a multiple of 8, so HW / 4 is a multiple of 16 rows), else 1 (every part
+// re-loads the whole padded image: 60 -> 71 us at B = 4096) -- StatsRef{m_tile = HW / parts, n_tiles = 1}
+int conv_in_parts(int Hp, int Wp, int B) { return (B < 256 && (Hp * Wp) % 64 == 0) ? 4 : 1; }
 
 hipError_t launch_conv_in(const float* x, const float* w, float* dst, double* stats, int B, int H0, int D,
                           int Hp, int Wp, int lh, int lw, int* step_dev, int* t_dev, const int* timesteps, int n_steps,
@@ -81,7 +82,7 @@ hipError_t launch_conv_in(const float* x, const float* w, float* dst, double* st
     const size_t lds = (size_t)(HW + 8) * sizeof(float);
     if (lds > 64 * 1024 || B <= 0) return hipErrorInvalidValue;
     if (adv >= -1 && (!step_dev || !t_dev || !timesteps || n_steps < 1)) return hipErrorInvalidValue;
-    const int parts = conv_in_parts(Hp, Wp);
+    const int parts = conv_in_parts(Hp, Wp, B);
     const StepAdvance sa{step_dev, t_dev, timesteps, n_steps, adv};
     hipLaunchKernelGGL(conv_in_kernel, dim3(B, parts), dim3(256), lds, s, x, w, dst, stats, stats_slots(HW, HW / parts, 1), H0, D,
                        Hp, Wp, lh, lw, sa);

@@ -153,7 +153,7 @@ inline std::vector<float> frag_order_weights(const std::vector<float>& split, in
 // ---- streaming / small kernels (elementwise.hip) -------------------------------------------
 // first conv, Cin = 1, fused zero-padding of the (H0, D) trajectory to (Hp, Wp)
 // ... and, as the first kernel of a denoise step, the loop bookkeeping (adv: -2 none, -1 advance by one, >= 0 set the step)
-int conv_in_parts(int Hp, int Wp);        // row parts per sample = statistics slots it writes (m_tile = HW / parts)
+int conv_in_parts(int Hp, int Wp, int B);        // row parts per sample = statistics slots it writes (m_tile = HW / parts)
 hipError_t launch_conv_in(const float* x, const float* w /*[9][64]*/, float* dst, double* stats,
                           int B, int H0, int D, int Hp, int Wp, int lh, int lw, int* step_dev, int* t_dev,
                           const int* timesteps_dev, int n_steps, int adv, hipStream_t s);

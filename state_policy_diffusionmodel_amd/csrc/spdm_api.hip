@@ -747,7 +747,8 @@ struct Ctx {
         // dry run that sizes the arena is not): 128-row x 64-wide tiles, or the split-K combine kernel's row groups
         const int slots_max = std::max(std::max(std::max(slots, stats_slots(HW, 128, std::max(1, C / 64))),   // (coarser tilings need fewer)
                                                 stats_slots(HW, combine_rows(HW, C), 1)),
-                                       stats_slots(HW, 16, std::max(1, C / 32)));                      // conv_skinny's finest tiling
+                                       std::max(stats_slots(HW, 16, std::max(1, C / 32)),              // conv_skinny's finest tiling
+                                                stats_slots(HW, std::max(HW / 4, 1), 1)));             // conv_in_kernel's four row parts
         size_t off = 0;
         if (!h->arena.alloc(sizeof(double) * 2 * (size_t)B * slots_max, &off)) {
             if (!err) err = fail(SPDM_ERR_NOMEM, "workspace exhausted (batch %d)", B);
@@ -962,7 +963,7 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
     // ---- inc = DoubleConvolution(1, 64) on the zero-padded trajectory (:286-288) ----
     Value v0;
     v0.t = c.talloc(64, 0);
-    v0.st = c.salloc(c.HWl(0), 64, c.HWl(0) / conv_in_parts(h->Hp, h->Wp), 1);
+    v0.st = c.salloc(c.HWl(0), 64, c.HWl(0) / conv_in_parts(h->Hp, h->Wp, B), 1);
     v0.gamma = h->inc.gamma; v0.beta = h->inc.beta;
     if (!c.err && !c.dry)
         c.check(launch_conv_in(x, h->w_inc_first, v0.t.p, v0.st.p, B, h->cfg.horizon, h->cfg.state_dim, h->Hp, h->Wp,
