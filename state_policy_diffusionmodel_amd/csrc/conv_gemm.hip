@@ -760,6 +760,20 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
         g.slots = stats_slots(HW, g.st_m_tile, g.st_n_tiles);
         return g;
     }
+    // tuning override (tools/autotune_convs.py): SPDM_TUNE5 / 6 / 7 = forced m_tile / n_tile / ksplit of the statistics-epilogue convs
+    if (stats_epi && split && taps != 1 && spdm_tune(5, 0) > 0) {
+        g.m_tile = spdm_tune(5, 0);
+        g.n_tile = spdm_tune(6, 64);
+        g.ksplit = std::max(1, spdm_tune(7, 1));
+        if (N % g.n_tile != 0 || (g.m_tile != 128 && g.m_tile != 256)) { g.n_tile = 64; g.m_tile = 128; }
+        g.n_tiles = N / g.n_tile;
+        if (g.ksplit > K / CK) g.ksplit = K / CK;
+        while (g.ksplit > 1 && (size_t)g.ksplit * M * N * sizeof(float) > SPLITK_WORKSPACE_BYTES) --g.ksplit;
+        if (g.ksplit > 1) { g.st_m_tile = combine_rows(HW, N); g.st_n_tiles = 1; }
+        else { g.st_m_tile = g.m_tile; g.st_n_tiles = g.n_tiles; }
+        g.slots = stats_slots(HW, g.st_m_tile, g.st_n_tiles);
+        return g;
+    }
     const int nt128 = (N % 128 == 0) ? N / 128 : 0;
     const int nt_pref = nt128 ? nt128 : N / 64;
     bool big = split && taps != 1 && M >= 256;
