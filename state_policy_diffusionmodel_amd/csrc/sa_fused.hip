@@ -310,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 sa_split(kt[8 * sub + j] * 16.0f, h, l);
                 k_h[j] = h; k_l[j] = l;
             }
+#ifndef SA_ABLATE_NOKV
             __syncthreads();                        // every wave is done with the previous head's K / V^T
             *reinterpret_cast<s_f16x8*>(Khi + t * SA_KROW + 8 * kh) = k_h;
             *reinterpret_cast<s_f16x8*>(Klo + t * SA_KROW + 8 * kh) = k_l;
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             }
             __syncthreads();
 
+#endif
             // ---- flash attention of this wave's 32 queries over all key blocks ----
             s_f32x16 acc_o;
 #pragma unroll
@@ -359,7 +361,11 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 dst_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka_l_, q_h, dst_, 0, 0, 0);                                \
             }
             constexpr bool AHEAD = !PAIR && SA_SCORES_AHEAD;
+#ifdef SA_ABLATE_NOLOOP
+            const int nkb = (a.L < 0) ? 1 : 0;                  // timing experiment: no attention loop at all (wrong results)
+#else
             const int nkb = (L + 31) / 32;                      // key blocks that hold at least one real token
+#endif
             s_f32x16 acc_n;
             if constexpr (AHEAD) SA_SCORES(acc_n, 0)
             for (int kb = 0; kb < nkb; ++kb) {
@@ -451,6 +457,9 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             for (int j = 0; j < 4; ++j) av[T][4 * g + j] += v[j];
         }
     }
+#ifdef SA_ABLATE_NOFF
+    if (a.L < 0) {
+#endif
     // ---- feed-forward: LN -> W1 -> GELU -> W2 -> + av ----
     if (WLDS) {                                     // phase B of the staged weights (every wave is past the out-proj reads)
         __syncthreads();
@@ -483,6 +492,11 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         f[T] = WLDS ? sa_gemm_tile_lds(Wsh, Wsl, 64 + 32 * T, li, kh, bh, bl, f[T]) : sa_gemm_tile(a.w2_h, a.w2_l, 32 * T, li, kh, bh, bl, f[T]);
         sa_bias(f[T], a.b2, T, kh);
     }
+#ifdef SA_ABLATE_NOFF
+    }
+    s_f32x16 f[2];
+    for (int T = 0; T < 2; ++T) for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
+#endif
     if (t < L) {
         float* orow = a.out + ((size_t)b * L + t) * SA_C;
 #pragma unroll
