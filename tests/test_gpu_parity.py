@@ -421,3 +421,35 @@ def test_split_range_guard_activations():
         assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
     finally:
         exact.close()
+
+
+@pytest.mark.parametrize("H,D", [(32, 3), (64, 6), (24, 5)], ids=["h32d3", "h64d6", "h24d5"])
+def test_every_batch_regime_agrees_with_single_trajectory_runs(H, D):
+    """Kernel selection (tile sizes, split-K, the few-row kernel, 128- vs 256-row tiles, width-2 rules ...) depends on the
+    batch.  Sweep batches across every regime boundary and require each probed trajectory of the batch to equal the same
+    trajectory evaluated alone (itself oracle-checked above) to fp32 rounding.  A statistics-layout or tiling bug in any one
+    branch shows here as a 1e-3-sized deviation (this is the test that caught one)."""
+    cd = 33
+    sd = weights(cd, 21)
+    Bs = [2, 3, 5, 8, 9, 16, 33, 64, 100, 129, 200, 256, 300, 511, 512, 700, 1024, 1500, 2048]
+    if H == 64:
+        Bs = [2, 5, 8, 17, 64, 127, 128, 256, 300, 512, 1024]
+    Bmax = max(Bs)
+    g = torch.Generator().manual_seed(H * 10 + D)
+    x = torch.randn(Bmax, 1, H, D, generator=g).cuda()
+    y = torch.randn(Bmax, 1, 3, 11, generator=g).cuda()
+    eng = make_engine(H, D, cd, Bmax, sd)
+    try:
+        probes = sorted({0, 1, 2, Bmax // 3, Bmax - 1})
+        single = {i: eng.unet_forward(x[i:i + 1], [321], y[i:i + 1]).cpu()[0] for i in probes}
+        for B in Bs:
+            got = eng.unet_forward(x[:B], [321], y[:B]).cpu()
+            assert not eng.nonfinite()
+            for i in probes:
+                if i < B:
+                    d = float((got[i] - single[i]).abs().max())
+                    assert d <= 5e-6, (B, i, d)
+            last = eng.unet_forward(x[B - 1:B], [321], y[B - 1:B]).cpu()[0]       # the batch's last trajectory (ragged tiles)
+            assert float((got[B - 1] - last).abs().max()) <= 5e-6, (B, "last")
+    finally:
+        eng.close()
