@@ -57,6 +57,8 @@ def parse(argv=None):
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="collective backend (gloo + --stub-engine: CPU rehearsal of the launcher and the timing protocol)")
+    p.add_argument("--shared-device", action="store_true",
+                   help="every rank uses cuda:0 (rehearsal of the N > 1 path with the real engine on a 1-GPU box; use with --backend gloo)")
     p.add_argument("--stub-engine", action="store_true",
                    help="replace the HIP engine by a sleep (tests/test_bench_launcher.py only; the line says so)")
     return p.parse_args(argv)
@@ -251,6 +253,8 @@ def main():
         dev = torch.device("cpu")
         sync = lambda: None                                                     # noqa: E731
     else:
+        if args.shared_device:
+            local = 0
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
         sync = lambda: torch.cuda.synchronize(dev)                              # noqa: E731
@@ -322,7 +326,7 @@ def main():
             "vs_baseline": None, "data": "synthetic",
             "batch_steps_per_s": K / el,
             "config": {"workload": workload, "global_batch": world * B, "per_gpu_batch": B, "horizon": H, "state_dim": D,
-                       "parallelism": f"batch-shard x{world}"},
+                       "parallelism": f"batch-shard x{world}" + (" (REHEARSAL: all ranks on one GPU)" if args.shared_device else "")},
         }
         if stub:
             line["dtype"] = "none (stub engine: launcher rehearsal, no kernels)"
