@@ -801,7 +801,8 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
     // Width-2 maps (level 2): the 256-row kernels skip the zero-padding taps (a third of the MFMAs) and read half the weight
     // bytes per MFMA; keep that tiling and let split-K restore the grid (measured at B = 256 / 512 / 1024 on up1.dc1:
     // 83 -> 63, 126 -> 100 us; on width-4 maps the same trade LOSES 5-10 us per layer, so only here)
-    if (may_split && !big && split && taps == 9 && W == 2 && (HW & 7) == 0 && M >= 256 && K % 64 == 0 && spdm_tune(2, 1) != 0) {
+    // (K >= 256 only: with four chunks the combine pass costs more than the skipped taps save -- down2.dc1 at B = 2048: 48 vs 39 us)
+    if (may_split && !big && split && taps == 9 && W == 2 && (HW & 7) == 0 && M >= 256 && K % 64 == 0 && K >= 256 && spdm_tune(2, 1) != 0) {
         const long long t256 = (long long)((M + 255) / 256) * nt_pref;
         const int target = spdm_tune(0, 256);
         int S = (int)std::min<long long>(K / 64, (target + t256 - 1) / t256);
