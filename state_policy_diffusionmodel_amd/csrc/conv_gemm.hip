@@ -733,11 +733,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 // those would leave CUs idle (small batches / coarse levels).
 // tuning knobs for experiments (SPDM_TUNE0.. read once per process; defaults = the measured choice)
 int spdm_tune(int idx, int dflt) {
-    static int val[8];
-    static bool have[8], init = false;
+    constexpr int NT = 16;
+    static int val[NT];
+    static bool have[NT], init = false;
     if (!init) {
-        for (int i = 0; i < 8; ++i) {
-            char name[16];
+        for (int i = 0; i < NT; ++i) {
+            char name[20];
             snprintf(name, sizeof(name), "SPDM_TUNE%d", i);
             const char* e = getenv(name);
             have[i] = e != nullptr;
@@ -745,7 +746,7 @@ int spdm_tune(int idx, int dflt) {
         }
         init = true;
     }
-    return (idx >= 0 && idx < 8 && have[idx]) ? val[idx] : dflt;
+    return (idx >= 0 && idx < NT && have[idx]) ? val[idx] : dflt;
 }
 
 GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, bool stats_epi) {

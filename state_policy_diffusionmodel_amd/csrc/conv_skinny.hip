@@ -288,12 +288,22 @@ bool conv_skinny_geometry(int M, int N, int K, int HW, int W, int taps, int spli
     // Measured per layer at batch 1-8 (tools/bench_convs.py, SPDM_NO_SKINNY on / off; profiles/r02_skinny_vs_splitk.txt): this kernel
     // wins for <= 32 rows (6.5-10 us against 9-13.5 us for split-K launch + combine) and LOSES for 64-256 rows (17-26 against
     // 12-16: one m-tile x N / 32 workgroups is too few wave fronts for the slab staging and the weight stream), so: M <= 32.
-    if (!split || (sw & SW_NO_SKINNY) || M > 32 || M <= 0 || K % K_CK != 0 || N % 64 != 0 || W < 1 || W > 8) return false;
+    if (!split || (sw & SW_NO_SKINNY) || M <= 0 || K % K_CK != 0 || N % 64 != 0 || W < 1 || W > 8) return false;
     if (!(taps == 9 || (taps == 3 && W == 1)) || M % HW != 0) return false;
     int mt = M >= 64 ? 64 : M > 16 ? 32 : 16;
     while (mt > 16 && skinny_slab_bytes(mt, W, K) > (size_t)96 * 1024) mt >>= 1;
     if (skinny_slab_bytes(mt, W, K) > (size_t)150 * 1024) return false;
     const int mtiles = (M + mt - 1) / mt;
+    if (M > spdm_tune(8, 32)) {
+        // Beyond a handful of rows: only the 3-tap convolutions of the W == 1 level at medium batch, while the weight bytes all
+        // m-tiles together pull through L2 (every m-tile streams its N x K x taps weights) stay under ~110 MB: there this kernel
+        // (no partial slabs, no combine launch, 8-wave workgroups) beats split-K + combine -- 15-18 vs 17-25 us per layer at
+        // M = 1024, 15-18 vs 18-23 at 2048 for K = 256 -- and loses beyond (K = N = 512 at M = 2048: 201 MB, 36 vs 35 us).
+        // ... and the grid stays within one round of one workgroup per CU (bot1.a at M = 4096: 512 workgroups, 25 -> 32 us).
+        if (taps != 3 || M > 4096) return false;
+        const double mb = (double)mtiles * N * K * taps * 4.0 / 1.0e6;
+        if (mb > (double)spdm_tune(9, 110) || (long long)mtiles * (N / 64) > 256) return false;
+    }
     // 32-wide tiles when 64-wide ones would leave the grid under 32 workgroups (more wave fronts on the weight stream)
     const int nt = (mtiles * (N / 64) < 32) ? 32 : 64;
     *m_tile = mt;

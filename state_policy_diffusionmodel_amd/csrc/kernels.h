@@ -70,6 +70,7 @@ inline const SwitchName* switch_table(int* n) {
     return t;
 }
 unsigned switches_from_env();          // spdm_api.hip
+int spdm_tune(int idx, int dflt);      // conv_gemm.hip: SPDM_TUNE<idx> (read once per process) or dflt -- tuning experiments only
 
 enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_GELU = 2 };
 enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RESID = 3, EPI_PLAIN = 4 };
