@@ -214,6 +214,12 @@ int  spdm_encoder_create(int32_t device, const float* h_blob, size_t n_floats, c
 int  spdm_encoder_forward(spdm_encoder* e, int32_t n_images, const float* d_images, float* d_latent, void* stream);
 void spdm_encoder_destroy(spdm_encoder* e);
 
+/* Host-only test hook (no GPU call): the launch geometry chosen for a split-precision 3x3 / 3x1 convolution with the
+ * statistics epilogue -- out = {m_tile, n_tile, n_tiles, slots, ksplit, skinny, st_m_tile, st_n_tiles, reserved_slots,
+ * combine_rows}.  `switches` = 0 for the defaults. */
+int  spdm_debug_geometry(int32_t M, int32_t N, int32_t K, int32_t HW, int32_t W, int32_t taps, uint32_t switches,
+                         int32_t out[10]);
+
 /* Op-level test hook: d_y = GELU(d_x) evaluated with the device erf that the conv prologues use
  * (nn.GELU(), models/Unet_FiLmLayer.py:104). */
 int  spdm_op_gelu(const float* d_x, float* d_y, size_t n, void* stream);

@@ -53,6 +53,7 @@ SYMBOLS = {
     "spdm_encoder_forward": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "spdm_encoder_destroy": (None, [c_void_p]),
     "spdm_op_gelu": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "spdm_debug_geometry": (c_int32, [c_int32] * 6 + [ctypes.c_uint32, POINTER(c_int32 * 10)]),
     "spdm_bench_gemm": (c_int32, [c_int32] * 12 + [POINTER(c_double)]),   # ms_out[2]: {ms per launch, max|split - fp32|}
 }
 

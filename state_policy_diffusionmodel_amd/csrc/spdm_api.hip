@@ -1587,6 +1587,21 @@ extern "C" int spdm_encoder_forward(spdm_encoder* e, int32_t n_images, const flo
     return SPDM_OK;
 }
 
+// Host-only introspection (no GPU): the launch geometry gemm_geometry picks for a statistics-epilogue convolution, plus the
+// statistics-slot reservation the plan makes for it (Ctx::salloc).  tests/test_geometry.py checks the invariants between the
+// two on a grid of shapes (a mismatch is a silent wrong-statistics bug on the GPU).
+extern "C" int spdm_debug_geometry(int32_t M, int32_t N, int32_t K, int32_t HW, int32_t W, int32_t taps, uint32_t switches,
+                                   int32_t out[10]) {
+    if (!out || M <= 0 || N <= 0 || K <= 0 || HW <= 0 || W <= 0 || M % HW != 0) return fail(SPDM_ERR_INVALID, "bad argument");
+    const GemmGeom g = gemm_geometry(M, N, K, HW, W, taps, /*split=*/1, switches, /*stats_epi=*/true);
+    out[0] = g.m_tile; out[1] = g.n_tile; out[2] = g.n_tiles; out[3] = g.slots; out[4] = g.ksplit; out[5] = g.skinny;
+    out[6] = g.st_m_tile; out[7] = g.st_n_tiles;
+    out[8] = std::max(std::max(std::max(g.slots, stats_slots(HW, 128, std::max(1, N / 64))), stats_slots(HW, combine_rows(HW, N), 1)),
+                      std::max(stats_slots(HW, 16, std::max(1, N / 32)), stats_slots(HW, std::max(HW / 4, 1), 1)));   // = Ctx::salloc's reservation
+    out[9] = combine_rows(HW, N);
+    return SPDM_OK;
+}
+
 // op-level test hook: y = GELU(x) with the device's own erf (the one every conv prologue uses)
 extern "C" int spdm_op_gelu(const float* d_x, float* d_y, size_t n, void* stream) {
     if (!d_x || !d_y || n == 0) return fail(SPDM_ERR_INVALID, "bad argument");
