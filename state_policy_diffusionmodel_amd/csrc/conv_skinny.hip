@@ -285,27 +285,30 @@ static size_t skinny_slab_bytes(int m_tile, int W, int K) {
 
 // Shape rule (host): which launches run here, and their tile.  Returns false when the launch belongs to the other kernels.
 bool conv_skinny_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, int* m_tile, int* n_tile) {
-    // Measured per layer at batch 1-8 (tools/bench_convs.py, SPDM_NO_SKINNY on / off; profiles/r02_skinny_vs_splitk.txt): this kernel
-    // wins for <= 32 rows (6.5-10 us against 9-13.5 us for split-K launch + combine) and LOSES for 64-256 rows (17-26 against
-    // 12-16: one m-tile x N / 32 workgroups is too few wave fronts for the slab staging and the weight stream), so: M <= 32.
     if (!split || (sw & SW_NO_SKINNY) || M <= 0 || K % K_CK != 0 || N % 64 != 0 || W < 1 || W > 8) return false;
     if (!(taps == 9 || (taps == 3 && W == 1)) || M % HW != 0) return false;
-    int mt = M >= 64 ? 64 : M > 16 ? 32 : 16;
-    while (mt > 16 && skinny_slab_bytes(mt, W, K) > (size_t)96 * 1024) mt >>= 1;
-    if (skinny_slab_bytes(mt, W, K) > (size_t)150 * 1024) return false;
+    // Measured per layer at batch 1-256 against the split-K + combine launches of the larger kernels (tools/bench_convs.py with
+    // forced tiles, profiles/r02_skinny_rows.txt): this kernel wins wherever its grid -- 8-wave workgroups that each walk the WHOLE
+    // K range of a (rows x 64 columns) tile -- stays within one workgroup per CU, and the MORE workgroups the better: 16-row
+    // tiles beat 32- and 64-row ones at the same shape (level 0-1 at batch 1: 15 -> 8.5 us per layer, 64-row tiles 19; level 3
+    // at 1024 rows: 9-10 us against 14-17 with 64-row tiles), although every m-tile streams the layer's weights again (they come
+    // from L2: up to 300 MB per launch at 20 us).  Past 256 workgroups it loses (level 0 at batch 32+: 30 vs 25 us).
+    // So: the smallest row tile whose grid fits 256 workgroups; 64-row tiles only for the 3-tap convolutions of the W == 1 level
+    // (M <= 4096, <= ~110 MB of weight reads: K = N = 512 at M = 2048 is 201 MB and a tie; 9-tap 64-row tiles lose everywhere).
+    const int gmax = spdm_tune(8, 256);
+    int mt = 0;
+    for (int cand = 16; cand <= 64 && mt == 0; cand <<= 1)
+        if ((long long)((M + cand - 1) / cand) * (N / 64) <= gmax && skinny_slab_bytes(cand, W, K) <= (size_t)96 * 1024) mt = cand;
+    if (const int cap = spdm_tune(10, 0); mt != 0 && (cap == 16 || cap == 32 || cap == 64) && cap >= mt) mt = cap;   // (tuning experiments: a coarser tile)
+    if (mt == 0) return false;
     const int mtiles = (M + mt - 1) / mt;
-    if (M > spdm_tune(8, 32)) {
-        // Beyond a handful of rows: only the 3-tap convolutions of the W == 1 level at medium batch, while the weight bytes all
-        // m-tiles together pull through L2 (every m-tile streams its N x K x taps weights) stay under ~110 MB: there this kernel
-        // (no partial slabs, no combine launch, 8-wave workgroups) beats split-K + combine -- 15-18 vs 17-25 us per layer at
-        // M = 1024, 15-18 vs 18-23 at 2048 for K = 256 -- and loses beyond (K = N = 512 at M = 2048: 201 MB, 36 vs 35 us).
-        // ... and the grid stays within one round of one workgroup per CU (bot1.a at M = 4096: 512 workgroups, 25 -> 32 us).
-        if (taps != 3 || M > 4096) return false;
+    if (mt == 64) {
         const double mb = (double)mtiles * N * K * taps * 4.0 / 1.0e6;
-        if (mb > (double)spdm_tune(9, 110) || (long long)mtiles * (N / 64) > 256) return false;
+        if (taps != 3 || M > 4096 || mb > (double)spdm_tune(9, 110)) return false;
     }
-    // 32-wide tiles when 64-wide ones would leave the grid under 32 workgroups (more wave fronts on the weight stream)
-    const int nt = (mtiles * (N / 64) < 32) ? 32 : 64;
+    // 32-wide tiles when 64-wide ones would leave the grid under 128 workgroups (more wave fronts on the weight stream; all 31 layers
+    // at batch 8: 348 us with the threshold at 32, 331 at 64, 317 at 128, 307 always -- but always costs 7 % at batch 256)
+    const int nt = (mtiles * (N / 64) < spdm_tune(11, 128)) ? 32 : 64;
     *m_tile = mt;
     *n_tile = nt;
     return true;
