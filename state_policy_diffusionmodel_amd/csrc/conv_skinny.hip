@@ -295,10 +295,12 @@ bool conv_skinny_geometry(int M, int N, int K, int HW, int W, int taps, int spli
     // from L2: up to 300 MB per launch at 20 us).  Past 256 workgroups it loses (level 0 at batch 32+: 30 vs 25 us).
     // So: the smallest row tile whose grid fits 256 workgroups; 64-row tiles only for the 3-tap convolutions of the W == 1 level
     // (M <= 4096, <= ~110 MB of weight reads: K = N = 512 at M = 2048 is 201 MB and a tie; 9-tap 64-row tiles lose everywhere).
-    const int gmax = spdm_tune(8, 256);
+    const int gmax[3] = {spdm_tune(8, 256), spdm_tune(12, 256), spdm_tune(13, 256)};        // grid limit of the 16 / 32 / 64-row tiles
     int mt = 0;
-    for (int cand = 16; cand <= 64 && mt == 0; cand <<= 1)
-        if ((long long)((M + cand - 1) / cand) * (N / 64) <= gmax && skinny_slab_bytes(cand, W, K) <= (size_t)96 * 1024) mt = cand;
+    for (int i = 0; i < 3 && mt == 0; ++i) {
+        const int cand = 16 << i;
+        if ((long long)((M + cand - 1) / cand) * (N / 64) <= gmax[i] && skinny_slab_bytes(cand, W, K) <= (size_t)96 * 1024) mt = cand;
+    }
     if (const int cap = spdm_tune(10, 0); mt != 0 && (cap == 16 || cap == 32 || cap == 64) && cap >= mt) mt = cap;   // (tuning experiments: a coarser tile)
     if (mt == 0) return false;
     const int mtiles = (M + mt - 1) / mt;
