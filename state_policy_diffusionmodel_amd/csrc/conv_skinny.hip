@@ -50,7 +50,6 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l16 = lane & 15, kg = lane >> 4;
     const int HW = a.HW, W = a.W, H = a.H, M = a.M, K = a.K, N = a.N, taps = a.taps;
     const int halo = W + 1;
     const int QA = M_T + 2 * halo;            // slab rows of one chunk; row QA is all zero (what a masked tap reads)
@@ -63,6 +62,39 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     float* Abuf = smem;                                   // [nch][QZ][K_LDK]
     float* smean = Abuf + (size_t)nch * QZ * K_LDK;       // [NS]
     float* srstd = smean + NS;                            // [NS]
+
+    // ---- the loads nothing depends on go out first: this wave's first weight item and the first batch of slab pieces (a launch of
+    //      this kernel is a chain of dependent memory round trips -- statistics, slab, weights -- so they are overlapped) ----
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int nitem = nch * taps;
+    // B operands: fragment-order weights, block ((tap nch + chunk) N/16 + nb16) x {hi, lo} of 256 floats
+    const float* wfl = a.wgt_frag + ((size_t)(n0 >> 4) * 2) * 256 + lane * 4;
+    const size_t wtap = (size_t)(N >> 4) * 2 * 256;          // floats per (tap, chunk)
+    k_f16x8 fb[2][CT][2];
+#define SKINNY_LOAD_B(slot_, item_)                                                                  \
+    {                                                                                                \
+        const int it_ = min((item_), nitem - 1);                                                     \
+        const int ch_ = it_ / taps, tp_ = it_ - ch_ * taps;                                          \
+        const float* p_ = wfl + (size_t)(tp_ * nch + ch_) * wtap;                                    \
+        _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_) {                                         \
+            fb[slot_][c_][0] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512);                     \
+            fb[slot_][c_][1] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512 + 256);               \
+        }                                                                                            \
+    }
+    SKINNY_LOAD_B(0, wave)
+    const int npiece = nch * QA * 8;                          // slab pieces: (chunk, row q, 16-byte part c4)
+    k_f32x4 v[8];
+    int qs[8], cs[8];
+#define SKINNY_LOAD_A(p0_)                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
+        const int p = min((p0_) + j * K_NTHR + tid, npiece - 1);                                     \
+        const int c4 = p & 7, rq = p >> 3;                                                           \
+        const int q = rq % QA, ch = rq / QA;                                                         \
+        const int m = min(max(m0 - halo + q, 0), M - 1);                                             \
+        qs[j] = q; cs[j] = ch * 8 + c4;                                                              \
+        v[j] = *reinterpret_cast<const k_f32x4*>(a.src + (size_t)m * a.src_ld + ch * K_CK + c4 * 4); \
+    }
+    SKINNY_LOAD_A(0)
 
     // ---- statistics of the samples the slab touches ----
     int bh_first = 0;
@@ -80,47 +112,35 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     for (int t = tid; t < nch * K_LDK; t += K_NTHR) Abuf[((t / K_LDK) * QZ + QA) * K_LDK + t % K_LDK] = 0.f;
     if (pro) __syncthreads();
 
-    // ---- stage the whole slab: piece p = (chunk, row q, 16-byte part c4); 8 pieces in flight per thread ----
-    {
-        const int npiece = nch * QA * 8;
-        for (int p0 = 0; p0 < npiece; p0 += K_NTHR * 8) {
-            k_f32x4 v[8];
-            int qs[8], cs[8];
+    // ---- stage the whole slab: 8 pieces in flight per thread (the first batch was issued above) ----
+    for (int p0 = 0; p0 < npiece; p0 += K_NTHR * 8) {
+        if (p0) SKINNY_LOAD_A(p0)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int p = min(p0 + j * K_NTHR + tid, npiece - 1);
-                const int c4 = p & 7, rq = p >> 3;
-                const int q = rq % QA, ch = rq / QA;
-                const int m = min(max(m0 - halo + q, 0), M - 1);
-                qs[j] = q; cs[j] = ch * 8 + c4;
-                v[j] = *reinterpret_cast<const k_f32x4*>(a.src + (size_t)m * a.src_ld + ch * K_CK + c4 * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (p0 + j * K_NTHR + tid < npiece) {
-                    const int q = qs[j], ch = cs[j] >> 3, c4 = cs[j] & 7;
-                    const int m = m0 - halo + q;
-                    k_f32x4 x = v[j];
-                    if (pro) {
-                        const int bi = min(max(m, 0), M - 1) / HW - bh_first;
-                        const float rs = srstd[bi], mu = smean[bi];
-                        const k_f32x4 g4 = *reinterpret_cast<const k_f32x4*>(a.pro_gamma + ch * K_CK + c4 * 4);
-                        const k_f32x4 b4 = *reinterpret_cast<const k_f32x4*>(a.pro_beta + ch * K_CK + c4 * 4);
-                        x.x = (x.x - mu) * (rs * g4.x) + b4.x;
-                        x.y = (x.y - mu) * (rs * g4.y) + b4.y;
-                        x.z = (x.z - mu) * (rs * g4.z) + b4.z;
-                        x.w = (x.w - mu) * (rs * g4.w) + b4.w;
-                        if (pro_gelu) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
-                    }
-                    if (m < 0 || m >= M) x = k_f32x4{0.f, 0.f, 0.f, 0.f};
-                    const k_f32x2 p0_ = ksplit2(x.x, x.y), p1_ = ksplit2(x.z, x.w);
-                    float* row = Abuf + ((size_t)ch * QZ + q) * K_LDK;
-                    *reinterpret_cast<k_f32x2*>(row + c4 * 2) = k_f32x2{p0_.x, p1_.x};        // hi
-                    *reinterpret_cast<k_f32x2*>(row + 16 + c4 * 2) = k_f32x2{p0_.y, p1_.y};   // lo
+        for (int j = 0; j < 8; ++j) {
+            if (p0 + j * K_NTHR + tid < npiece) {
+                const int q = qs[j], ch = cs[j] >> 3, c4 = cs[j] & 7;
+                const int m = m0 - halo + q;
+                k_f32x4 x = v[j];
+                if (pro) {
+                    const int bi = min(max(m, 0), M - 1) / HW - bh_first;
+                    const float rs = srstd[bi], mu = smean[bi];
+                    const k_f32x4 g4 = *reinterpret_cast<const k_f32x4*>(a.pro_gamma + ch * K_CK + c4 * 4);
+                    const k_f32x4 b4 = *reinterpret_cast<const k_f32x4*>(a.pro_beta + ch * K_CK + c4 * 4);
+                    x.x = (x.x - mu) * (rs * g4.x) + b4.x;
+                    x.y = (x.y - mu) * (rs * g4.y) + b4.y;
+                    x.z = (x.z - mu) * (rs * g4.z) + b4.z;
+                    x.w = (x.w - mu) * (rs * g4.w) + b4.w;
+                    if (pro_gelu) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
                 }
+                if (m < 0 || m >= M) x = k_f32x4{0.f, 0.f, 0.f, 0.f};
+                const k_f32x2 p0_ = ksplit2(x.x, x.y), p1_ = ksplit2(x.z, x.w);
+                float* row = Abuf + ((size_t)ch * QZ + q) * K_LDK;
+                *reinterpret_cast<k_f32x2*>(row + c4 * 2) = k_f32x2{p0_.x, p1_.x};        // hi
+                *reinterpret_cast<k_f32x2*>(row + 16 + c4 * 2) = k_f32x2{p0_.y, p1_.y};   // lo
             }
         }
     }
+#undef SKINNY_LOAD_A
 
     // ---- per-lane A rows and tap-validity masks (bit t of am[rt]: tap t of this lane's row in row tile rt is inside the image) ----
     unsigned am[RT];
@@ -142,9 +162,6 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     }
     const int aoff0 = (l16 + halo) * K_LDK + kg * 4;
     const int zoff = QA * K_LDK + kg * 4;
-    // B operands: fragment-order weights, block ((tap nch + chunk) N/16 + nb16) x {hi, lo} of 256 floats
-    const float* wfl = a.wgt_frag + ((size_t)(n0 >> 4) * 2) * 256 + lane * 4;
-    const size_t wtap = (size_t)(N >> 4) * 2 * 256;          // floats per (tap, chunk)
 
     k_f32x4 acc[RT][CT];
 #pragma unroll
@@ -154,20 +171,7 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
 
     __syncthreads();                                          // slab complete
 
-    // ---- this wave's items: i = wave, wave + 8, ... over (chunk, tap), chunk-major ----
-    const int nitem = nch * taps;
-    k_f16x8 fb[2][CT][2];
-#define SKINNY_LOAD_B(slot_, item_)                                                                  \
-    {                                                                                                \
-        const int it_ = min((item_), nitem - 1);                                                     \
-        const int ch_ = it_ / taps, tp_ = it_ - ch_ * taps;                                          \
-        const float* p_ = wfl + (size_t)(tp_ * nch + ch_) * wtap;                                    \
-        _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_) {                                         \
-            fb[slot_][c_][0] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512);                     \
-            fb[slot_][c_][1] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512 + 256);               \
-        }                                                                                            \
-    }
-    SKINNY_LOAD_B(0, wave)
+    // ---- this wave's items: i = wave, wave + 8, ... over (chunk, tap), chunk-major (item `wave` is already in flight) ----
     int slot = 0;
     for (int item = wave; item < nitem; item += 2 * K_WAVES) {
 #pragma unroll
