@@ -312,9 +312,14 @@ bool conv_skinny_geometry(int M, int N, int K, int HW, int W, int taps, int spli
         const double mb = (double)mtiles * N * K * taps * 4.0 / 1.0e6;
         if (taps != 3 || M > 4096 || mb > (double)spdm_tune(9, 110)) return false;
     }
-    // 32-wide tiles when 64-wide ones would leave the grid under 128 workgroups (more wave fronts on the weight stream; all 31 layers
-    // at batch 8: 348 us with the threshold at 32, 331 at 64, 317 at 128, 307 always -- but always costs 7 % at batch 256)
-    const int nt = (mtiles * (N / 64) < spdm_tune(11, 128)) ? 32 : 64;
+    // 32-wide tiles unless 64-wide ones already fill the chip (256 workgroups): the weight stream of a launch moves through more
+    // CUs.  Timed on the WHOLE step (graph replay, tools/probes/step_tune.sh) -- the per-layer micro-benchmark re-reads hot weights
+    // and misleads here: it preferred 16-wide tiles (batch 1: 290 -> 269 us over the 31 layers), which make the step SLOWER
+    // (0.653 -> 0.677 ms at batch 1: 2-KB weight bursts from cold HBM/MALL); so they stay off (SPDM_TUNE14).  Step time with the
+    // 32-wide limit at 32 / 128 / 256 workgroups: batch 8 0.725 / 0.694 / 0.688, batch 32 0.810 / 0.789 / 0.771, batch 64
+    // - / 0.878 / 0.858 ms; 32-wide at exactly 256 (512 workgroups) costs 4-6 %.
+    const int g64 = mtiles * (N / 64);
+    const int nt = (g64 < spdm_tune(14, 0)) ? 16 : (g64 < spdm_tune(11, 256)) ? 32 : 64;
     *m_tile = mt;
     *n_tile = nt;
     return true;
@@ -333,6 +338,9 @@ hipError_t launch_conv_skinny(const GemmArgs& a, const GemmGeom& g, hipStream_t 
         if (g.m_tile == 64) return launch_skinny_rc<4, 2>(a, g, s);
         if (g.m_tile == 32) return launch_skinny_rc<2, 2>(a, g, s);
         if (g.m_tile == 16) return launch_skinny_rc<1, 2>(a, g, s);
+    } else if (g.n_tile == 16) {
+        if (g.m_tile == 32) return launch_skinny_rc<2, 1>(a, g, s);
+        if (g.m_tile == 16) return launch_skinny_rc<1, 1>(a, g, s);
     }
     return hipErrorInvalidValue;
 }

@@ -747,7 +747,7 @@ struct Ctx {
         // dry run that sizes the arena is not): 128-row x 64-wide tiles, or the split-K combine kernel's row groups
         const int slots_max = std::max(std::max(std::max(slots, stats_slots(HW, 128, std::max(1, C / 64))),   // (coarser tilings need fewer)
                                                 stats_slots(HW, combine_rows(HW, C), 1)),
-                                       std::max(stats_slots(HW, 16, std::max(1, C / 32)),              // conv_skinny's finest tiling
+                                       std::max(stats_slots(HW, 16, std::max(1, C / 16)),              // conv_skinny's finest tiling
                                                 stats_slots(HW, std::max(HW / 4, 1), 1)));             // conv_in_kernel's four row parts
         size_t off = 0;
         if (!h->arena.alloc(sizeof(double) * 2 * (size_t)B * slots_max, &off)) {
@@ -1597,7 +1597,7 @@ extern "C" int spdm_debug_geometry(int32_t M, int32_t N, int32_t K, int32_t HW, 
     out[0] = g.m_tile; out[1] = g.n_tile; out[2] = g.n_tiles; out[3] = g.slots; out[4] = g.ksplit; out[5] = g.skinny;
     out[6] = g.st_m_tile; out[7] = g.st_n_tiles;
     out[8] = std::max(std::max(std::max(g.slots, stats_slots(HW, 128, std::max(1, N / 64))), stats_slots(HW, combine_rows(HW, N), 1)),
-                      std::max(stats_slots(HW, 16, std::max(1, N / 32)), stats_slots(HW, std::max(HW / 4, 1), 1)));   // = Ctx::salloc's reservation
+                      std::max(stats_slots(HW, 16, std::max(1, N / 16)), stats_slots(HW, std::max(HW / 4, 1), 1)));   // = Ctx::salloc's reservation
     out[9] = combine_rows(HW, N);
     return SPDM_OK;
 }
