@@ -808,7 +808,7 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
         const int target = spdm_tune(0, 256);
         int S = (int)std::min<long long>(K / 64, (target + t256 - 1) / t256);
         while (S > 1 && (size_t)S * M * N * sizeof(float) > SPLITK_WORKSPACE_BYTES) --S;
-        if (t256 * S >= target * 3 / 4 && S <= spdm_tune(3, 4)) {
+        if (t256 * S >= target * 3 / 4 && S <= spdm_tune(3, 8)) {
             g.m_tile = 256; g.n_tile = nt128 ? 128 : 64; g.n_tiles = N / g.n_tile; g.ksplit = S;
             if (S > 1) { g.st_m_tile = combine_rows(HW, N); g.st_n_tiles = 1; }      // the combine kernel writes the statistics
             else { g.st_m_tile = g.m_tile; g.st_n_tiles = g.n_tiles; }               // (S == 1: the plain 256-row launch)

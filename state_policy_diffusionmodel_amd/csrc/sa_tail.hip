@@ -288,7 +288,10 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
     tf16x8 fb[2][CT][2], fa[2][2];
     tf32x4 acc[RT][CT], v[NP];
 
-    TAIL_LOAD_B(0, a.wf, 0)
+    // small grids: gridDim.y = 3 workgroups per row tile, one of q / k / v each (the weight stream of the launch through three
+    // times as many CUs; the LayerNorm of the rows is recomputed by each)
+    const int g_lo = (int)blockIdx.y * 3 / (int)gridDim.y, g_hi = ((int)blockIdx.y + 1) * 3 / (int)gridDim.y;
+    TAIL_LOAD_B(0, a.wf + (size_t)g_lo * WPROD, 0)
     {
         const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
         const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
@@ -310,15 +313,14 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
     }
     TAIL_WRITE_SLAB(v)
     __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
+    for (int g = g_lo; g < g_hi; ++g) {
         const float* wg = a.wf + (size_t)g * WPROD;
         const float* wnext = a.wf + (size_t)(g < 2 ? g + 1 : g) * WPROD;       // the last trailing prefetch re-reads a valid block
         TAIL_GEMM(wg, wnext)
         // accumulators -> LDS: the slab must survive for the next product, so the tile goes BEHIND it
         {
             float* ot = smem + NCH * T_M * T_LDK;
-            if (g > 0) __syncthreads();                 // every thread has picked up the previous product's rows
+            if (g > g_lo) __syncthreads();              // every thread has picked up the previous product's rows
 #pragma unroll
             for (int rt_ = 0; rt_ < RT; ++rt_)
 #pragma unroll
@@ -380,8 +382,10 @@ hipError_t launch_sa_qkv(int C, const float* x, float* qkv, int rows, const floa
     const size_t lds = (size_t)((C / 32) * TM * T_LDK + TM * C) * sizeof(float);     // slab 36.9 KB + output tile 32 KB
     const void* kern = C == 128 ? reinterpret_cast<const void*>(sa_qkv_kernel<128>) : reinterpret_cast<const void*>(sa_qkv_kernel<256>);
     if (hipError_t e = allow_full_lds(kern); e != hipSuccess) return e;
-    if (C == 128) hipLaunchKernelGGL(sa_qkv_kernel<128>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(sa_qkv_kernel<256>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
+    const int tiles = (rows + TM - 1) / TM;
+    const int gy = (tiles < spdm_tune(15, 512)) ? 3 : 1;      // q, k, v on a workgroup each while the grid is small
+    if (C == 128) hipLaunchKernelGGL(sa_qkv_kernel<128>, dim3(tiles, gy), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(sa_qkv_kernel<256>, dim3(tiles, gy), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
