@@ -102,11 +102,13 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
         const int lo = max(m0 - halo, 0), hi = min(m0 + M_T + halo, M) - 1;
         bh_first = lo / HW;
         const int bh_last = hi / HW;
-        for (int t = tid; t <= bh_last - bh_first; t += K_NTHR) {
+        for (int t = wave; t <= bh_last - bh_first; t += K_WAVES) {          // one wave per sample
             float mean, rstd;
-            sample_mean_rstd(a.pro_stats, bh_first + t, mean, rstd);
-            smean[t] = mean;
-            srstd[t] = rstd;
+            sample_mean_rstd_wave(a.pro_stats, bh_first + t, lane, mean, rstd);
+            if (lane == 0) {
+                smean[t] = mean;
+                srstd[t] = rstd;
+            }
         }
     }
     for (int t = tid; t < nch * K_LDK; t += K_NTHR) Abuf[((t / K_LDK) * QZ + QA) * K_LDK + t % K_LDK] = 0.f;

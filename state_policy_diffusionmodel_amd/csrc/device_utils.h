@@ -22,6 +22,34 @@ __device__ __forceinline__ void sample_mean_rstd(const StatsRef& st, int b, floa
     rstd = (float)(1.0 / sqrt(var + 1e-5));
 }
 
+// The same for a whole wave (all 64 lanes call it, all get the result).  The fine tilings of the small-grid kernels leave up to
+// ~130 partial slots per sample (16-row x 32-column tiles); one thread adding them one after the other was 3-6 us of a 9-15 us
+// launch at batch 1.  Few slots: lane order as above (same bits as the serial form); many: lane i adds slots i, i + 64, ...
+// and a fixed butterfly adds the lanes -- deterministic, independent of the batch.
+__device__ __forceinline__ void sample_mean_rstd_wave(const StatsRef& st, int b, int lane, float& mean, float& rstd) {
+    const long long r0 = (long long)b * st.HW;
+    const int first = (int)(r0 / st.m_tile);
+    const int last = (int)((r0 + st.HW - 1) / st.m_tile);
+    const int n = (last - first + 1) * st.n_tiles;
+    if (n <= 8) {                       // (wave-uniform)
+        sample_mean_rstd(st, b, mean, rstd);
+        return;
+    }
+    const double* p = st.p + (size_t)b * st.slots * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < n; i += 64) { s1 += p[2 * i]; s2 += p[2 * i + 1]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    const double m = s1 * st.inv_count;
+    double var = s2 * st.inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + 1e-5));
+}
+
 // erf(x), branch-free.  Same two minimax pieces the ROCm device library's erff uses (|x| < 1: odd
 // polynomial; |x| >= 1: 1 - exp(-q(|x|))), but both evaluated and SELECTED instead of branched: inside a
 // wave the library version almost always executes both sides of its divergent branch anyway, plus the

@@ -94,11 +94,13 @@ __device__ __forceinline__ void block_sample_stats(const AffineSrc& src, int b, 
     mean = 0.f;
     rstd = 1.f;
     if (src.st.p != nullptr) {
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 64) {                                   // the first wave adds the partial slots together
             float m, r;
-            sample_mean_rstd(src.st, b, m, r);
-            sm[0] = m;
-            sm[1] = r;
+            sample_mean_rstd_wave(src.st, b, (int)threadIdx.x, m, r);
+            if (threadIdx.x == 0) {
+                sm[0] = m;
+                sm[1] = r;
+            }
         }
         __syncthreads();
         mean = sm[0];
