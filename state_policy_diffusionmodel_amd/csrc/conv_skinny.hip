@@ -232,24 +232,32 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
         srow[(r * (N_T / 4) + c4) * 2 + 1] = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
     }
     __syncthreads();
-    // per-sample totals, fixed order, fp64: one thread per sample the tile touches
+    // per-sample totals in fp64, one WAVE per sample the tile touches: lane i adds the entries i, i + 64, ... of the sample's
+    // rows, a fixed butterfly adds the lanes (deterministic; one thread walking 128 entries was ~1.5 us of every launch)
     {
         const int t_lo = m0, t_hi = min(m0 + M_T, M);
         if (t_hi > t_lo) {
             const int b_first = t_lo / HW, b_last = (t_hi - 1) / HW;
-            for (int t = tid; t <= b_last - b_first; t += K_NTHR) {
+            for (int t = wave; t <= b_last - b_first; t += K_WAVES) {
                 const int b = b_first + t;
                 const int r_lo = max(b * HW, t_lo) - m0, r_hi = min((b + 1) * HW, t_hi) - m0;
+                const int e_lo = r_lo * (N_T / 4), e_hi = r_hi * (N_T / 4);          // srow entries [e_lo, e_hi) are contiguous
                 double s1 = 0.0, s2 = 0.0;
-                for (int r = r_lo; r < r_hi; ++r)
-                    for (int c4 = 0; c4 < N_T / 4; ++c4) {
-                        s1 += (double)srow[(r * (N_T / 4) + c4) * 2];
-                        s2 += (double)srow[(r * (N_T / 4) + c4) * 2 + 1];
-                    }
-                const int slot2 = (mtile - (b * HW) / M_T) * n_ntiles + ntile;
-                double* o = a.epi_stats + ((size_t)b * epi_slots + slot2) * 2;
-                o[0] = s1;
-                o[1] = s2;
+                for (int e = e_lo + lane; e < e_hi; e += 64) {
+                    s1 += (double)srow[e * 2];
+                    s2 += (double)srow[e * 2 + 1];
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (lane == 0) {
+                    const int slot2 = (mtile - (b * HW) / M_T) * n_ntiles + ntile;
+                    double* o = a.epi_stats + ((size_t)b * epi_slots + slot2) * 2;
+                    o[0] = s1;
+                    o[1] = s2;
+                }
             }
         }
     }
