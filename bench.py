@@ -52,6 +52,8 @@ def parse(argv=None):
     p.add_argument("--kind", default="ddpm", choices=["ddpm", "ddim"])
     p.add_argument("--train-steps", type=int, default=1000)
     p.add_argument("--no-attention", action="store_true")
+    p.add_argument("--instrument-steps", type=int, default=2,
+                   help="how many of the K timed steps carry per-launch HIP events (the rest replay as hipGraphs, the product's path); 0 = all")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-batch", type=int, default=64)
     p.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -186,7 +188,7 @@ class StubEngine:
         pass
 
 
-def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, profile, sync):
+def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, profile, sync, instr=2):
     """W untimed + exactly K timed denoise steps of one workload on this rank's shard, all-gather included; returns
     (max-over-ranks seconds, conv launches, conv ms, conv flops, graph-replay seconds or None, final iterates)."""
     import torch
@@ -203,11 +205,22 @@ def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, p
     eng.sample_run(0, W)                                   # untimed warm-up steps
     if world > 1:
         dist.all_gather_into_tensor(gathered, x_T.contiguous())   # untimed: the backend sets its channels up on the first call of a kind
+    # The timed region is EXACTLY K denoise steps: the first K - P the way the product runs them (spdm_sample_run replays each
+    # step as a hipGraph), the last P with HIP events around every run of consecutive conv3x3 launches on the launch stream --
+    # what `roofline` is measured from (events cannot sit inside a replayed graph, and instrumenting all K steps with plain
+    # launches timed a path the product does not take: 1 % slower at 4096 trajectories per GPU, 8 % at 512).
+    # --instrument-steps 0 instruments all K.
+    # (a graph is captured on the first call of >= 3 steps: the warm-up must have done that, or nothing is replayed here)
+    P = K if (not profile or instr <= 0 or K - instr < 3 or W < 3) else min(instr, K)
     if profile:
-        eng.profile(True)                                  # HIP events around every run of consecutive conv3x3 launches
+        eng.profile("prepare")                             # events created here, outside the timed region
     barrier()
     t0 = time.perf_counter()
-    eng.sample_run(W, W + K)                               # EXACTLY K denoise steps
+    if K - P > 0:
+        eng.sample_run(W, W + K - P)
+    if profile:
+        eng.profile(True)
+    eng.sample_run(W + K - P, W + K)
     out = eng.sample_result()
     if world > 1:
         dist.all_gather_into_tensor(gathered, out.contiguous())   # RCCL over xGMI, closes the timed region
@@ -232,7 +245,7 @@ def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, p
     el = float(tmax[0].item())
     if el_graph is not None:
         el_graph = float(tmax[1].item())
-    return el, launches, conv_ms, conv_flops, el_graph, out
+    return el, launches, conv_ms, conv_flops, el_graph, out, (P if profile else 0)
 
 
 def main():
@@ -305,11 +318,12 @@ def main():
     for mode in modes:
         B = Bw if mode == "weak" else Bs
         cond, x_T, inpaint = inputs(B, rank * B)
-        el, launches, conv_ms, conv_flops, el_graph, out = timed_run(
-            eng, dist, world, dev, cond, x_T, inpaint, rank * B, W, K, T, profile=True, sync=sync)
+        el, launches, conv_ms, conv_flops, el_graph, out, instr_steps = timed_run(
+            eng, dist, world, dev, cond, x_T, inpaint, rank * B, W, K, T, profile=True, sync=sync, instr=args.instrument_steps)
         if not bool(torch.isfinite(out).all()):
             raise SystemExit("bench: non-finite iterate")
-        runs[mode] = dict(B=B, el=el, launches=launches, conv_ms=conv_ms, conv_flops=conv_flops, el_graph=el_graph)
+        runs[mode] = dict(B=B, el=el, launches=launches, conv_ms=conv_ms, conv_flops=conv_flops, el_graph=el_graph,
+                          instr_steps=instr_steps)
 
     if rank == 0:
         r = runs[headline]
@@ -338,7 +352,8 @@ def main():
             line["roofline"] = roofline(args, r, split, B, H, D, el, K)
             if r["el_graph"] is not None:
                 line["graph_replay"] = {"ms_per_step": r["el_graph"] / K * 1e3, "value": world * B * K / r["el_graph"],
-                                        "note": "same K steps replayed as a hipGraph per step, no per-launch events (max over ranks)"}
+                                        "note": "K more steps, ALL replayed as hipGraphs, no per-launch events (max over ranks); the timed "
+                                                "region itself replays K - P steps and instruments the last P (roofline.instrumented_steps)"}
         for mode, rr in runs.items():
             if mode != headline:
                 line[f"{mode}_scaling"] = {"value": world * rr["B"] * K / rr["el"], "ms_per_step": rr["el"] / K * 1e3,
@@ -389,7 +404,8 @@ def roofline(args, r, split, B, H, D, el, K):
            "fp32_mfma_peak_tflops": 157.3,
            "traffic": traffic, "traffic_source": src,
            "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
-           "share_of_step_time": conv_ms / (el * 1e3)}
+           "instrumented_steps": r.get("instr_steps", K), "graph_replay_steps": K - r.get("instr_steps", K),
+           "share_of_step_time": (conv_ms / max(r.get("instr_steps", K), 1)) / (el / K * 1e3)}
     if hbm_step is not None:
         gbs = float(hbm_step) / (el / K) / 1e9
         out.update({"hbm_bytes_per_step": float(hbm_step), "hbm_achieved_GBps": gbs, "hbm_peak_GBps": 8000.0, "hbm_frac": gbs / 8000.0})

@@ -190,7 +190,10 @@ size_t spdm_device_bytes(const spdm_handle* h);
 /* Device time of the dominant kernel class, measured with HIP events on the
  * launch stream: when enabled, every conv3x3 implicit-GEMM launch is bracketed
  * by events; spdm_profile_read returns launches, total ms and total FLOPs
- * since the last reset.  For bench.py's roofline leg only (adds sync points). */
+ * since the last reset.  For bench.py's roofline leg only (adds sync points).
+ * on = 1: instrument from now on (runs are plain launches, not graph replays);
+ * on = 0: stop; on = 2: only create the events ahead of time (nothing is
+ * instrumented, graph replay stays on) so that a later on = 1 costs nothing. */
 int  spdm_profile_enable(spdm_handle* h, int32_t on);
 int  spdm_profile_read(spdm_handle* h, int64_t* launches, double* total_ms, double* total_flops);
 

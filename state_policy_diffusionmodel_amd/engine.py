@@ -243,8 +243,10 @@ class SpdmEngine:
                    "spdm_debug_tensor")
         return buf.permute(0, 3, 1, 2).contiguous()
 
-    def profile(self, on: bool) -> None:
-        _lib.check(self.lib.spdm_profile_enable(self._h, int(on)), "spdm_profile_enable")
+    def profile(self, on) -> None:
+        """True / False: per-launch HIP events on / off; "prepare": create the events now, instrument nothing yet."""
+        mode = 2 if on == "prepare" else int(bool(on))
+        _lib.check(self.lib.spdm_profile_enable(self._h, mode), "spdm_profile_enable")
 
     def profile_read(self):
         n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
