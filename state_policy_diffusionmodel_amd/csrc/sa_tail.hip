@@ -88,8 +88,16 @@ __device__ __forceinline__ void tail_film_fold(tf32x4 (&v)[8], const float* __re
     }
 }
 
+#ifdef SPDM_DIAG_TAIL
+__device__ unsigned long long g_tail_stamps[64];      // diagnostic builds: phase stamps of workgroup 0 (s_memrealtime, 10 ns ticks)
+#define TAIL_STAMP(k_) if (blockIdx.x == 0 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_tail_stamps[(C == 256 ? 16 : 0) + (k_)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define TAIL_STAMP(k_)
+#endif
+
 template <int C>
 __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
+    TAIL_STAMP(0)
     using S = TailShape<C>;
     constexpr int T_C = C, T_M = S::TM, NCH = S::NCH, RPP = S::RPP, TPR = S::TPR;
     constexpr int RT = 2, CT = 4;                       // per wave: 32 rows x 64 columns = 2 x 4 tiles of 16 x 16
@@ -188,12 +196,15 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     }
     if (a.ab != nullptr) tail_film_fold<C>(av, a.ab, a.L, m0, M, c16, srow0);
     __syncthreads();
+    TAIL_STAMP(1)
 
     tf32x4 acc[RT][CT];
 
     // ---- av = o W_o^T + b_o + x ;  slab <- LayerNorm(av) ----
     TAIL_GEMM(a.wf_o, a.wf_1)
+    TAIL_STAMP(2)
     TAIL_ACC_TO_TILE()
+    TAIL_STAMP(3)
     {
         const tf32x4 bo = *reinterpret_cast<const tf32x4*>(a.b_o + c16 * 4);
         const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
@@ -217,9 +228,11 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     __syncthreads();                                    // every thread has read its pieces of the tile
     TAIL_WRITE_SLAB(v)
     __syncthreads();
+    TAIL_STAMP(4)
 
     // ---- f1 = GELU(ln W_1^T + b_1) ;  slab <- f1 ----
     TAIL_GEMM(a.wf_1, a.wf_2)
+    TAIL_STAMP(5)
     TAIL_ACC_TO_TILE()
     {
         const tf32x4 b1 = *reinterpret_cast<const tf32x4*>(a.b_1 + c16 * 4);
@@ -234,9 +247,11 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     __syncthreads();
     TAIL_WRITE_SLAB(v)
     __syncthreads();
+    TAIL_STAMP(6)
 
     // ---- out = f1 W_2^T + b_2 + av ----
     TAIL_GEMM(a.wf_2, a.wf_2)                           // (the trailing prefetch re-reads a valid block; unused)
+    TAIL_STAMP(7)
     TAIL_ACC_TO_TILE()
     {
         const tf32x4 b2 = *reinterpret_cast<const tf32x4*>(a.b_2 + c16 * 4);
@@ -251,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
             }
         }
     }
+    TAIL_STAMP(8)
 }
 
 // ---- the head of the same blocks:  qkv = LayerNorm(x) W_in^T + b_in   (self.ln -> mha in_proj, :76-79) -----------
@@ -352,6 +368,12 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
 }
 
 }  // namespace
+
+#ifdef SPDM_DIAG_TAIL
+extern "C" int spdm_debug_tail_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tail_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool sa_tail_supported(int C, unsigned sw) { return (C == 128 || C == 256) && !(sw & SW_NO_SA_TAIL); }
 
