@@ -178,6 +178,12 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     }
 
     TAIL_LOAD_B(0, a.wf_o, 0)
+    // the per-column parameters of every phase, fetched now: loaded where they are used, each cost its phase a memory round trip
+    const tf32x4 bo = *reinterpret_cast<const tf32x4*>(a.b_o + c16 * 4);
+    const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
+    const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
+    const tf32x4 b1 = *reinterpret_cast<const tf32x4*>(a.b_1 + c16 * 4);
+    const tf32x4 b2 = *reinterpret_cast<const tf32x4*>(a.b_2 + c16 * 4);
 
     // ---- slab <- o (attention output), raw ----
     tf32x4 av[NP], v[NP];
@@ -206,9 +212,10 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     TAIL_ACC_TO_TILE()
     TAIL_STAMP(3)
     {
-        const tf32x4 bo = *reinterpret_cast<const tf32x4*>(a.b_o + c16 * 4);
-        const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
-        const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
+        // LayerNorm over each row's C values (two-pass, like torch): a row sits on TPR consecutive lanes.  The NP row pieces of a
+        // thread go through the two cross-lane sums TOGETHER (NP independent shuffle chains in flight): one piece at a time the
+        // phase was 3.4-3.7 us of a 13-16 us launch -- longer than any of the three products (tools/probes/tail_stamps.py).
+        float part[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int r = RPP * i + srow0;
@@ -216,13 +223,29 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
             t += bo;
             t += av[i];
             av[i] = t;
-            // LayerNorm over the row's C values (two-pass, like torch): the row sits on TPR consecutive lanes
-            const float mean = trow_sum<TPR>((t.x + t.y) + (t.z + t.w)) * (1.0f / (float)C);
+            part[i] = (t.x + t.y) + (t.z + t.w);
+        }
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) part[i] += __shfl_xor(part[i], o, 64);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float mean = part[i] * (1.0f / (float)C);
+            const tf32x4 t = av[i];
             const tf32x4 d = {t.x - mean, t.y - mean, t.z - mean, t.w - mean};
-            const float var = trow_sum<TPR>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / (float)C);
-            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);        // v_rsq_f32 (1 ulp)
+            v[i] = d;
+            part[i] = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) part[i] += __shfl_xor(part[i], o, 64);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float rstd = __builtin_amdgcn_rsqf(part[i] * (1.0f / (float)C) + 1e-5f);        // v_rsq_f32 (1 ulp)
+            const tf32x4 d = v[i];
             v[i] = tf32x4{d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w};
-            __builtin_amdgcn_sched_barrier(0);          // one row piece at a time: register pressure
         }
     }
     __syncthreads();                                    // every thread has read its pieces of the tile
@@ -235,14 +258,12 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     TAIL_STAMP(5)
     TAIL_ACC_TO_TILE()
     {
-        const tf32x4 b1 = *reinterpret_cast<const tf32x4*>(a.b_1 + c16 * 4);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             tf32x4 t = *reinterpret_cast<const tf32x4*>(otile + (RPP * i + srow0) * T_C + c16 * 4);
             t += b1;
-            v[i] = tf32x4{gelu_erf(t.x), gelu_erf(t.y), gelu_erf(t.z), gelu_erf(t.w)};
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            v[i] = tf32x4{gelu_erf(t.x), gelu_erf(t.y), gelu_erf(t.z), gelu_erf(t.w)};      // (no scheduling fence between pieces: the
+        }                                                                                   //  erf chains of the NP pieces interleave)
     }
     __syncthreads();
     TAIL_WRITE_SLAB(v)
@@ -254,7 +275,6 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     TAIL_STAMP(7)
     TAIL_ACC_TO_TILE()
     {
-        const tf32x4 b2 = *reinterpret_cast<const tf32x4*>(a.b_2 + c16 * 4);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int r = RPP * i + srow0;
@@ -332,6 +352,7 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
     for (int g = g_lo; g < g_hi; ++g) {
         const float* wg = a.wf + (size_t)g * WPROD;
         const float* wnext = a.wf + (size_t)(g < 2 ? g + 1 : g) * WPROD;       // the last trailing prefetch re-reads a valid block
+        const tf32x4 bi = *reinterpret_cast<const tf32x4*>(a.b_in + g * T_C + c16 * 4);     // (in flight during the product)
         TAIL_GEMM(wg, wnext)
         // accumulators -> LDS: the slab must survive for the next product, so the tile goes BEHIND it
         {
@@ -347,7 +368,6 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
                         ot[(wm * 32 + rt_ * 16 + 4 * kg + j_) * T_C + col_] = acc[rt_][ct_][j_] * T_DESCALE;
                 }
             __syncthreads();
-            const tf32x4 bi = *reinterpret_cast<const tf32x4*>(a.b_in + g * T_C + c16 * 4);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int r = RPP * i + srow0;
