@@ -92,18 +92,6 @@ __device__ __forceinline__ f32x2 split2(float a, float b) {
     return f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 
-// Sum over the 16 lanes of a DPP row (quad swaps, half-mirror, mirror): every lane ends with the row total.
-__device__ __forceinline__ float row16_sum_dpp(float v) {
-#define DPP_ADD(ctrl_)                                                                                          \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, false));
-    DPP_ADD(0xB1)       // quad_perm [1,0,3,2]
-    DPP_ADD(0x4E)       // quad_perm [2,3,0,1]
-    DPP_ADD(0x141)      // row_half_mirror
-    DPP_ADD(0x140)      // row_mirror
-#undef DPP_ADD
-    return v;
-}
-
 template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE>
 // launch bound (256, 2): a 256-register budget.  The 8 x 2 variants with a prologue then carry 88-128 bytes of scratch per lane
 // (stats finalisation state parked across the main loop); with (256, 1) the compiler allocates 203-250 registers and no scratch,

@@ -50,6 +50,19 @@ __device__ __forceinline__ void sample_mean_rstd_wave(const StatsRef& st, int b,
     rstd = (float)(1.0 / sqrt(var + 1e-5));
 }
 
+// Sum over the 16 lanes of a DPP row (quad swaps, half-mirror, mirror): every lane ends with the row total.  Four VALU
+// operations, no LDS traffic; the same additions as the xor butterfly 1, 2, 4, 8 (a + b == b + a), so bit-identical to it.
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+#define DPP_ADD(ctrl_)                                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, false));
+    DPP_ADD(0xB1)       // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E)       // quad_perm [2,3,0,1]
+    DPP_ADD(0x141)      // row_half_mirror
+    DPP_ADD(0x140)      // row_mirror
+#undef DPP_ADD
+    return v;
+}
+
 // erf(x), branch-free.  Same two minimax pieces the ROCm device library's erff uses (|x| < 1: odd
 // polynomial; |x| >= 1: 1 - exp(-q(|x|))), but both evaluated and SELECTED instead of branched: inside a
 // wave the library version almost always executes both sides of its divergent branch anyway, plus the

@@ -62,10 +62,14 @@ __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
     return tf32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 // sum over the TPR consecutive lanes that hold one row (32: a half-wave; 64: the wave)
+// (the first four butterfly steps inside the DPP rows -- VALU only; 16 and 32 through ds_bpermute: a LayerNorm phase of
+//  8 row pieces x 2 sums x 5-6 bpermutes per thread was bound by the LDS crossbar)
 template <int TPR>
 __device__ __forceinline__ float trow_sum(float v) {
+    static_assert(TPR == 32 || TPR == 64, "rows of 32 or 64 lanes");
+    v = row16_sum_dpp(v);
 #pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 16; o < TPR; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
@@ -226,7 +230,9 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
             part[i] = (t.x + t.y) + (t.z + t.w);
         }
 #pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1)
+        for (int i = 0; i < NP; ++i) part[i] = row16_sum_dpp(part[i]);
+#pragma unroll
+        for (int o = 16; o < TPR; o <<= 1)
 #pragma unroll
             for (int i = 0; i < NP; ++i) part[i] += __shfl_xor(part[i], o, 64);
 #pragma unroll
@@ -238,7 +244,9 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
             part[i] = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
         }
 #pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1)
+        for (int i = 0; i < NP; ++i) part[i] = row16_sum_dpp(part[i]);
+#pragma unroll
+        for (int o = 16; o < TPR; o <<= 1)
 #pragma unroll
             for (int i = 0; i < NP; ++i) part[i] += __shfl_xor(part[i], o, 64);
 #pragma unroll
