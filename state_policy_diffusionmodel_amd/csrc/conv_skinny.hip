@@ -42,12 +42,23 @@ __device__ __forceinline__ k_f32x2 ksplit2(float a, float b) {
     return k_f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 
+#ifdef SPDM_DIAG_SKINNY
+// diagnostic builds: phase stamps (s_memrealtime, 10-ns ticks) of workgroup 0, thread 0 of the launch with (K, N) == g_skinny_sel
+__device__ unsigned long long g_skinny_stamps[16];
+__device__ int g_skinny_sel[2];
+#define SKINNY_STAMP(k_) if (blockIdx.x == 0 && threadIdx.x == 0 && a.K == g_skinny_sel[0] && a.N == g_skinny_sel[1]) { \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_skinny_stamps[k_] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define SKINNY_STAMP(k_)
+#endif
+
 // RT row tiles of 16 (M_T = 16 RT), CT column tiles of 16 (N_T = 16 CT)
 template <int RT, int CT, int PRO>
 __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a, const int epi_slots, const int NS) {
     constexpr int M_T = RT * 16, N_T = CT * 16;
     constexpr bool pro = (PRO != PRO_NONE), pro_gelu = (PRO == PRO_GN_GELU);
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    SKINNY_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = a.HW, W = a.W, H = a.H, M = a.M, K = a.K, N = a.N, taps = a.taps;
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     }
     for (int t = tid; t < nch * K_LDK; t += K_NTHR) Abuf[((t / K_LDK) * QZ + QA) * K_LDK + t % K_LDK] = 0.f;
     if (pro) __syncthreads();
+    SKINNY_STAMP(1)
 
     // ---- stage the whole slab: 8 pieces in flight per thread (the first batch was issued above) ----
     for (int p0 = 0; p0 < npiece; p0 += K_NTHR * 8) {
@@ -172,6 +184,7 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = k_f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();                                          // slab complete
+    SKINNY_STAMP(2)
 
     // ---- this wave's items: i = wave, wave + 8, ... over (chunk, tap), chunk-major (item `wave` is already in flight) ----
     int slot = 0;
@@ -205,7 +218,9 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     (void)slot;
 
     // ---- cross-wave reduction in the fixed order w = 0..7 (the slab is dead) ----
+    SKINNY_STAMP(3)
     __syncthreads();
+    SKINNY_STAMP(4)
     float* red = smem;                                        // [8 waves][M_T][N_T] fp32
     // accumulator layout: lane (l16, kg), register j of tile (rt, ct) = row 16 rt + 4 kg + j, column 16 ct + l16
 #pragma unroll
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
             for (int j = 0; j < 4; ++j)
                 red[((size_t)wave * M_T + rt * 16 + 4 * kg + j) * N_T + ct * 16 + l16] = acc[rt][ct][j];
     __syncthreads();
+    SKINNY_STAMP(5)
 
     // thread -> (row, 4 columns); M_T * N_T / 4 pieces over 512 threads
     constexpr int NPIECE = M_T * N_T / 4;
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
         srow[(r * (N_T / 4) + c4) * 2 + 1] = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
     }
     __syncthreads();
+    SKINNY_STAMP(6)
     // per-sample totals in fp64, one WAVE per sample the tile touches: lane i adds the entries i, i + 64, ... of the sample's
     // rows, a fixed butterfly adds the lanes (deterministic; one thread walking 128 entries was ~1.5 us of every launch)
     {
@@ -261,6 +278,7 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
             }
         }
     }
+    SKINNY_STAMP(7)
 }
 
 template <int RT, int CT>
@@ -291,6 +309,16 @@ hipError_t launch_skinny_rc(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
 }
 
 }  // namespace
+
+#ifdef SPDM_DIAG_SKINNY
+extern "C" int spdm_debug_skinny_select(int K, int N) {
+    const int sel[2] = {K, N};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_skinny_sel), sel, sizeof(sel)) == hipSuccess ? 0 : -1;
+}
+extern "C" int spdm_debug_skinny_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_skinny_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // LDS bytes of the up-front slab for a tile of m_tile rows
 static size_t skinny_slab_bytes(int m_tile, int W, int K) {
