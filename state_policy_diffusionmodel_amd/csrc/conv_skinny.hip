@@ -187,21 +187,37 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     SKINNY_STAMP(2)
 
     // ---- this wave's items: i = wave, wave + 8, ... over (chunk, tap), chunk-major (item `wave` is already in flight) ----
-    int slot = 0;
+    // The (chunk, tap) pair of an item is STEPPED, not divided out: per item a wave has only 6 RT MFMAs, and the two runtime
+    // integer divisions (~80 scalar instructions) were most of the 0.26 us an item took (phase stamps + ISA, tools/probes/skinny_stamps.py).
+    const int is9 = (taps == 9) ? 1 : 0;
+    const int dch = K_WAVES / taps, dtp = K_WAVES - dch * taps;       // one step of K_WAVES items in (chunk, tap)
+#define SKINNY_STEP(ch_, tp_) { tp_ += dtp; ch_ += dch; if (tp_ >= taps) { tp_ -= taps; ++ch_; } }
+    int cch = wave / taps, ctp = wave - cch * taps;                    // the item being multiplied
+    int wch = cch, wtp = ctp;                                          // the item whose weights are fetched next
+    SKINNY_STEP(wch, wtp)
+#define SKINNY_LOAD_B2(slot_)                                                                        \
+    {                                                                                                \
+        const float* p_ = wfl + (size_t)(wtp * nch + min(wch, nch - 1)) * wtap;                      \
+        _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_) {                                         \
+            fb[slot_][c_][0] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512);                     \
+            fb[slot_][c_][1] = *reinterpret_cast<const k_f16x8*>(p_ + c_ * 512 + 256);               \
+        }                                                                                            \
+        SKINNY_STEP(wch, wtp)                                                                        \
+    }
     for (int item = wave; item < nitem; item += 2 * K_WAVES) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int it = item + half * K_WAVES;
-            SKINNY_LOAD_B(1 - half, it + K_WAVES)              // unconditional prefetch (clamped past the end)
+            SKINNY_LOAD_B2(1 - half)                           // unconditional prefetch (clamped past the end)
+            __builtin_amdgcn_sched_barrier(0);                 // (pinned: the compiler otherwise sinks the prefetch below the MFMAs)
             if (it < nitem) {
-                const int ch = it / taps, tp = it - ch * taps;
-                const int dh = (taps == 9) ? tp / 3 - 1 : tp - 1;
-                const int dw = (taps == 9) ? tp - (tp / 3) * 3 - 1 : 0;
-                const float* Ab = Abuf + (size_t)ch * QZ * K_LDK;
+                const int q3 = (ctp * 11) >> 5;                // ctp / 3 for ctp < 9
+                const int dh = is9 * q3 + (1 - is9) * ctp - 1, dw = is9 * (ctp - 3 * q3 - 1);
+                const float* Ab = Abuf + (size_t)cch * QZ * K_LDK;
                 const int shift = (dh * W + dw) * K_LDK;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    const int o = ((am[rt] >> tp) & 1u) ? aoff0 + rt * 16 * K_LDK + shift : zoff;
+                    const int o = ((am[rt] >> ctp) & 1u) ? aoff0 + rt * 16 * K_LDK + shift : zoff;
                     const k_f16x8 a_h = *reinterpret_cast<const k_f16x8*>(Ab + o);
                     const k_f16x8 a_l = *reinterpret_cast<const k_f16x8*>(Ab + o + 16);
 #pragma unroll
@@ -212,10 +228,13 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
                     }
                 }
             }
+            SKINNY_STEP(cch, ctp)
         }
     }
+#undef SKINNY_LOAD_B2
+#undef SKINNY_STEP
 #undef SKINNY_LOAD_B
-    (void)slot;
+
 
     // ---- cross-wave reduction in the fixed order w = 0..7 (the slab is dead) ----
     SKINNY_STAMP(3)
@@ -264,11 +283,8 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
                     s1 += (double)srow[e * 2];
                     s2 += (double)srow[e * 2 + 1];
                 }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
-                }
+                s1 = wave_sum_f64(s1);
+                s2 = wave_sum_f64(s2);
                 if (lane == 0) {
                     const int slot2 = (mtile - (b * HW) / M_T) * n_ntiles + ntile;
                     double* o = a.epi_stats + ((size_t)b * epi_slots + slot2) * 2;

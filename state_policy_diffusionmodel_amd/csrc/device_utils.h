@@ -22,6 +22,26 @@ __device__ __forceinline__ void sample_mean_rstd(const StatsRef& st, int b, floa
     rstd = (float)(1.0 / sqrt(var + 1e-5));
 }
 
+// Sum of a double over the 64 lanes of a wave, every lane ends with the total: the four in-row steps move the two halves by
+// DPP (VALU only), rows are joined by two ds_bpermute steps.  Fixed order: deterministic.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#define DPP_ADD64(ctrl_)                                                                                        \
+    {                                                                                                           \
+        const unsigned long long u_ = __builtin_bit_cast(unsigned long long, v);                                \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u_, ctrl_, 0xf, 0xf, false);             \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u_ >> 32), ctrl_, 0xf, 0xf, false);     \
+        v += __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi_ << 32) | (unsigned long long)(unsigned)lo_); \
+    }
+    DPP_ADD64(0xB1)      // quad_perm [1,0,3,2]
+    DPP_ADD64(0x4E)      // quad_perm [2,3,0,1]
+    DPP_ADD64(0x141)     // row_half_mirror
+    DPP_ADD64(0x140)     // row_mirror
+#undef DPP_ADD64
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // The same for a whole wave (all 64 lanes call it, all get the result).  The fine tilings of the small-grid kernels leave up to
 // ~130 partial slots per sample (16-row x 32-column tiles); one thread adding them one after the other was 3-6 us of a 9-15 us
 // launch at batch 1.  Few slots: lane order as above (same bits as the serial form); many: lane i adds slots i, i + 64, ...
@@ -38,11 +58,8 @@ __device__ __forceinline__ void sample_mean_rstd_wave(const StatsRef& st, int b,
     const double* p = st.p + (size_t)b * st.slots * 2;
     double s1 = 0.0, s2 = 0.0;
     for (int i = lane; i < n; i += 64) { s1 += p[2 * i]; s2 += p[2 * i + 1]; }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-    }
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
     const double m = s1 * st.inv_count;
     double var = s2 * st.inv_count - m * m;
     if (var < 0.0) var = 0.0;
