@@ -163,9 +163,22 @@ __device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&
 // PAIR (256 < L <= 512, horizons up to 64): TWO workgroups per trajectory, each owning 256 query tokens.  A block needs
 // K and V of all tokens, so every wave also projects K and V of its 32 partner tokens (same lane, other half) -- 2 extra
 // 32-row tile products per head pair, no exchange between workgroups.
+#ifdef SPDM_DIAG_SAF
+// diagnostic builds: phase stamps (s_memrealtime, 10-ns ticks) of workgroup 0, thread 0; FULL (L = 256) at 0.., the other at 32..
+__device__ unsigned long long g_saf_stamps[64];
+#define SAF_STAMP() if (blockIdx.x == 0 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        g_saf_stamps[(FULL ? 0 : 32) + (saf_n++)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define SAF_STAMP()
+#endif
+
 template <bool FULL, bool WLDS, bool PAIR>
 __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
+#ifdef SPDM_DIAG_SAF
+    int saf_n = 0;
+#endif
+    SAF_STAMP()
     const int L = a.L;
     const int nwave = blockDim.x >> 6;
     const int Lp = PAIR ? 2 * nwave * 32 : nwave * 32;
@@ -231,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         __syncthreads();
     }
 
+    SAF_STAMP()
     // (LayerNorm 1 and its B fragments are re-made per head pair inside the loop: 32 registers that need not live
     //  through the attention phase)
     s_f16x8 bh[4], bl[4];
@@ -273,6 +287,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             }
         }
 
+        SAF_STAMP()
         s_f32x16 kt2, vt2;
         if constexpr (PAIR) {
             {   // LayerNorm-1 fragments of the partner token (re-made per head pair, into the same registers)
@@ -344,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             __syncthreads();
 
 #endif
+            SAF_STAMP()
             // ---- flash attention of this wave's 32 queries over all key blocks ----
             s_f32x16 acc_o;
 #pragma unroll
@@ -419,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                     acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_l, p_h, acc_o, 0, 0, 0);
                 }
             }
+            SAF_STAMP()
             // accumulator row 16 / 20 (register 8): sum over ALL keys of 1.0 x p x 1024 -- the denominator, complete in both halves
             const float inv = 1.0f / (acc_o[8] * 16.0f);       // p carries x1024, v x16
 
@@ -440,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, o_l, av[T], 0, 0, 0);
                 av[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, o_h, av[T], 0, 0, 0);
             }
+            SAF_STAMP()
         }
     }
 
@@ -457,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             for (int j = 0; j < 4; ++j) av[T][4 * g + j] += v[j];
         }
     }
+    SAF_STAMP()
 #ifdef SA_ABLATE_NOFF
     if (a.L < 0) {
 #endif
@@ -469,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         sa_stage_rows(Wsl, 64, a.w2_l, 64, tid, blockDim.x);
         __syncthreads();
     }
+    SAF_STAMP()
     {
         s_f32x16 ln[2];
         sa_layernorm(av, ln, a.ln2_g, a.ln2_b, kh);
@@ -485,6 +505,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         for (int r = 0; r < 16; ++r) f[T][r] = gelu_erf(f[T][r]);
     }
     sa_make_frags(f, bh, bl);
+    SAF_STAMP()
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
@@ -497,6 +518,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     s_f32x16 f[2];
     for (int T = 0; T < 2; ++T) for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
 #endif
+    SAF_STAMP()
     if (t < L) {
         float* orow = a.out + ((size_t)b * L + t) * SA_C;
 #pragma unroll
@@ -508,7 +530,14 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                 *reinterpret_cast<s_f32x4*>(orow + 32 * T + 8 * g + 4 * kh) = v;
             }
     }
+    SAF_STAMP()
 }
+
+#ifdef SPDM_DIAG_SAF
+extern "C" int spdm_debug_saf_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_saf_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool sa_fused_supported(int L, int C) { return C == SA_C && L >= 1 && L <= 512; }
 
