@@ -122,6 +122,28 @@ __device__ __forceinline__ Affine4 make_affine(const AffineSrc& src, int c, floa
     }
     return a;
 }
+// the same in two halves: gamma / beta requested BEFORE the statistics are summed (one round trip less on the launch's chain)
+struct AffineParams { float4 g, be; bool on; };
+__device__ __forceinline__ AffineParams load_affine_params(const AffineSrc& src, int c) {
+    AffineParams p;
+    p.on = (src.st.p != nullptr);
+    p.g = make_float4(1.f, 1.f, 1.f, 1.f);
+    p.be = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.on) {
+        p.g = *reinterpret_cast<const float4*>(src.gamma + c);
+        p.be = *reinterpret_cast<const float4*>(src.beta + c);
+    }
+    return p;
+}
+__device__ __forceinline__ Affine4 finish_affine(const AffineParams& p, float mean, float rstd) {
+    Affine4 a;
+    a.on = p.on;
+    a.mu = mean;
+    a.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    a.be = p.be;
+    if (a.on) a.sc = make_float4(rstd * p.g.x, rstd * p.g.y, rstd * p.g.z, rstd * p.g.w);
+    return a;
+}
 __device__ __forceinline__ float4 apply_affine(const Affine4& a, float4 v) {
     if (a.on) {
         v.x = (v.x - a.mu) * a.sc.x + a.be.x;
@@ -139,12 +161,13 @@ __global__ __launch_bounds__(256) void pool_kernel(const AffineSrc src, float* _
                                                    int rows_per_block) {
     __shared__ float sm[2];
     const int b = blockIdx.x, tid = threadIdx.x;
-    float mean, rstd;
-    block_sample_stats(src, b, sm, mean, rstd);
     const int C = src.C, C4 = C >> 2;
     const int c4 = tid % C4, rl = tid / C4, rpp = 256 / C4;
     const int Ho = H >> 1, Wo = W >> 1, HWo = Ho * Wo;
-    const Affine4 af = make_affine(src, c4 * 4, mean, rstd);
+    const AffineParams ap = load_affine_params(src, c4 * 4);
+    float mean, rstd;
+    block_sample_stats(src, b, sm, mean, rstd);
+    const Affine4 af = finish_affine(ap, mean, rstd);
     const int r_end = min(HWo, (int)(blockIdx.y + 1) * rows_per_block);
     for (int ro = blockIdx.y * rows_per_block + rl; ro < r_end; ro += rpp) {
         const int ho = ro / Wo, wo = ro - ho * Wo;
@@ -185,9 +208,6 @@ __global__ __launch_bounds__(256) void upcat_kernel(const AffineSrc up, const Af
                                                     int Hin, int Win, int rows_per_block) {
     __shared__ float sm_u[2], sm_s[2];
     const int b = blockIdx.x, tid = threadIdx.x;
-    float mu_u, rs_u, mu_s, rs_s;
-    block_sample_stats(up, b, sm_u, mu_u, rs_u);
-    block_sample_stats(skip, b, sm_s, mu_s, rs_s);
     const int Cu = up.C, Cs = skip.C, C = Cu + Cs, C4 = C >> 2;
     // thread -> (row, 4-channel group).  When both halves are equally wide (every level of this U-Net) the first 128
     // threads take the upsampled channels and the last 128 the skip channels, so that a wave runs ONE of the two
@@ -205,7 +225,26 @@ __global__ __launch_bounds__(256) void upcat_kernel(const AffineSrc up, const Af
     const int Ho = 2 * Hin, Wo = 2 * Win, HWo = Ho * Wo;
     const bool is_up = (c4 * 4 < Cu);
     const int cl = is_up ? c4 * 4 : c4 * 4 - Cu;
-    const Affine4 af = is_up ? make_affine(up, cl, mu_u, rs_u) : make_affine(skip, cl, mu_s, rs_s);
+    const AffineParams ap = is_up ? load_affine_params(up, cl) : load_affine_params(skip, cl);      // before the statistics
+    // the statistics of both sources at once: wave 0 sums the slots of `up`, wave 1 those of `skip`; one barrier
+    float mu_u = 0.f, rs_u = 1.f, mu_s = 0.f, rs_s = 1.f;
+    if (up.st.p != nullptr || skip.st.p != nullptr) {
+        const int wv = tid >> 6, ln = tid & 63;
+        if (wv == 0 && up.st.p != nullptr) {
+            float m, r;
+            sample_mean_rstd_wave(up.st, b, ln, m, r);
+            if (ln == 0) { sm_u[0] = m; sm_u[1] = r; }
+        }
+        if (wv == 1 && skip.st.p != nullptr) {
+            float m, r;
+            sample_mean_rstd_wave(skip.st, b, ln, m, r);
+            if (ln == 0) { sm_s[0] = m; sm_s[1] = r; }
+        }
+        __syncthreads();
+        if (up.st.p != nullptr) { mu_u = sm_u[0]; rs_u = sm_u[1]; }
+        if (skip.st.p != nullptr) { mu_s = sm_s[0]; rs_s = sm_s[1]; }
+    }
+    const Affine4 af = is_up ? finish_affine(ap, mu_u, rs_u) : finish_affine(ap, mu_s, rs_s);
     const float sch = (Ho > 1) ? (float)(Hin - 1) / (float)(Ho - 1) : 0.f;
     const float scw = (Wo > 1) ? (float)(Win - 1) / (float)(Wo - 1) : 0.f;
     const int r_end = min(HWo, (int)(blockIdx.y + 1) * rows_per_block);
@@ -302,10 +341,27 @@ __global__ __launch_bounds__(256) void film_coef_kernel(const AffineSrc src, con
                                                         const float* __restrict__ film, float* __restrict__ ab) {
     __shared__ float sm[2];
     const int b = blockIdx.x;
+    const int C = src.C;
+    // everything that does not depend on the statistics is requested BEFORE they are summed (the launch is a chain of dependent
+    // round trips otherwise: slots -> barrier -> t -> temb row): channel c0 of this thread, the usual case C <= blockDim
+    const int c0 = threadIdx.x;
+    const bool has0 = c0 < C;
+    float g0 = 1.f, b0 = 0.f, e0 = 0.f, fs0 = 1.f, fb0 = 0.f;
+    if (has0) {
+        if (src.st.p != nullptr) { g0 = src.gamma[c0]; b0 = src.beta[c0]; }
+        if (temb != nullptr) e0 = temb[(size_t)t_dev[t_count == 1 ? 0 : b] * C + c0];
+        if (film != nullptr) { fs0 = film[(size_t)b * 2 * C + c0]; fb0 = film[(size_t)b * 2 * C + C + c0]; }
+    }
     float mean, rstd;
     block_sample_stats(src, b, sm, mean, rstd);
-    const int C = src.C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    if (has0) {
+        float sc = 1.f, be = 0.f;
+        if (src.st.p != nullptr) { sc = rstd * g0; be = b0 - mean * sc; }
+        be += e0;
+        ab[(size_t)b * 2 * C + c0] = fs0 * sc;
+        ab[(size_t)b * 2 * C + C + c0] = fs0 * be + fb0;
+    }
+    for (int c = c0 + blockDim.x; c < C; c += blockDim.x) {
         float sc = 1.f, be = 0.f;
         if (src.st.p != nullptr) { sc = rstd * src.gamma[c]; be = src.beta[c] - mean * sc; }
         if (temb != nullptr) be += temb[(size_t)t_dev[t_count == 1 ? 0 : b] * C + c];
