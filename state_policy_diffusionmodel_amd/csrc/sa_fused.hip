@@ -46,6 +46,7 @@ constexpr float SA_DESCALE = 1.0f / 2048.0f;      // act x16, weight x128
 
 struct SaFusedArgs {
     const float* x; float* out; int L;
+    int nb;                // trajectories (WLDS launches: persistent workgroups walk b = blockIdx.x, + gridDim.x, ...)
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     const _Float16 *wqkv_h, *wqkv_l, *wo_h, *wo_l, *w1_h, *w1_l, *w2_h, *w2_l;   // [rows][64] permuted, x128, in fragment order
     const float *bqkv, *bo, *b1, *b2;
@@ -167,7 +168,7 @@ __device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&
 // diagnostic builds: phase stamps (s_memrealtime, 10-ns ticks) of workgroup 0, thread 0; FULL (L = 256) at 0.., the other at 32..
 __device__ unsigned long long g_saf_stamps[64];
 #define SAF_STAMP() if (blockIdx.x == 0 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
-        g_saf_stamps[(FULL ? 0 : 32) + (saf_n++)] = __builtin_amdgcn_s_memrealtime(); }
+        if (saf_n < 30) g_saf_stamps[(FULL ? 0 : 32) + (saf_n++)] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define SAF_STAMP()
 #endif
@@ -183,16 +184,23 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     const int nwave = blockDim.x >> 6;
     const int Lp = PAIR ? 2 * nwave * 32 : nwave * 32;
     const int VROW = Lp + 8;                       // halfs per V^T row (16-byte aligned rows, 4-bank skew between rows)
-    _Float16* Khi = reinterpret_cast<_Float16*>(sa_smem);
-    _Float16* Klo = Khi + (size_t)Lp * SA_KROW;
-    _Float16* Vhi = Klo + (size_t)Lp * SA_KROW;    // [32][VROW], rows 16..31 stay zero
+    // LDS layout.  Without staged weights: K hi | K lo | V^T hi | V^T lo | FiLM row.  WLDS: V^T hi | V^T lo | W hi | W lo |
+    // FiLM row | K hi | K lo | spare -- the qkv / out-proj weights ([256][SA_WROW] hi and lo) stay resident for every trajectory
+    // the workgroup walks; ff1 / ff2 ([128][SA_WROW] hi and lo) are staged per trajectory over the K region + spare, which is
+    // dead once the last head's attention loop is done.
+    _Float16* const lds0 = reinterpret_cast<_Float16*>(sa_smem);
+    _Float16* Vhi = WLDS ? lds0 : lds0 + (size_t)2 * Lp * SA_KROW;      // [32][VROW], rows 16..31 constant
     _Float16* Vlo = Vhi + (size_t)32 * VROW;
-    _Float16* Wsh = Vlo + (size_t)32 * VROW;       // WLDS: [256][SA_WROW] hi rows: phase A qkv 0..191, out-proj 192..255; phase B w1 0..63, w2 64..127
+    _Float16* Wsh = Vlo + (size_t)32 * VROW;       // WLDS: [256][SA_WROW] hi rows: qkv 0..191, out-proj 192..255
     _Float16* Wsl = Wsh + (size_t)256 * SA_WROW;   //        [256][SA_WROW] lo rows
+    _Float16* Khi = WLDS ? Wsl + (size_t)256 * SA_WROW + 4 * SA_C : lds0;             // (4 SA_C halfs = the FiLM row's 2 SA_C floats)
+    _Float16* Klo = Khi + (size_t)Lp * SA_KROW;
+    _Float16* Fsh = Khi;                           // WLDS: [128][SA_WROW] hi rows of ff1 (0..63) and ff2 (64..127)
+    _Float16* Fsl = Fsh + (size_t)128 * SA_WROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
-    const int b = PAIR ? blockIdx.x >> 1 : blockIdx.x;
+    const int b_first = PAIR ? blockIdx.x >> 1 : blockIdx.x;
     const int hf = PAIR ? (blockIdx.x & 1) : 0;
     const int t = hf * 256 + wave * 32 + li;       // this lane's token
     const int t2 = (1 - hf) * 256 + wave * 32 + li;        // PAIR: the partner token whose K / V this lane also projects
@@ -201,7 +209,6 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     // swapped), which makes the 8 keys a lane half feeds to one P.V MFMA (4 kh + 0..3 and 8 + 4 kh + 0..3) contiguous
     const int tp = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
     const int tc = min(t, L - 1);
-    const float* xrow = a.x + ((size_t)b * L + tc) * SA_C;
 
     // rows 16..31 of V^T are written once (never overwritten): the d = 16 heads fill only half of a 32-row A tile.  Rows 16
     // and 20 are all ONES (hi part), the rest zero: the P.V product then leaves sum_keys p in accumulator register 8 of both
@@ -221,6 +228,14 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         __syncthreads();
     }
 
+    // WLDS: a persistent workgroup (the launch has one per CU) walks trajectories b_first, b_first + gridDim.x, ... with the
+    // weights above staged ONCE -- re-staging the same 74 KB per trajectory was 6 of the 52 us a trajectory took at B = 4096
+    // (phase stamps, profiles/r02_sa_fused_phases.txt).  Otherwise one trajectory per workgroup.
+    const int bstep = WLDS ? (int)gridDim.x : a.nb;
+    for (int b = b_first; b < a.nb; b += bstep) {
+    if (b != b_first) __syncthreads();              // every wave is done with the previous trajectory (FiLM row, ff weights)
+    const float* xrow = a.x + ((size_t)b * L + tc) * SA_C;
+
     // x^T tiles of a token: register r of tile T = feature 32 T + (r&3) + 8 (r>>2) + 4 kh.  They are (re)loaded where they
     // are used (twice for LayerNorm 1, once for the residual: L2 hits) instead of living in 32 registers throughout.
 #define SA_LOAD_X(dst_, row_)                                                                            \
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
         }
     // FiLM tail folded into the load (film_coef_kernel): the sample's [A | B] sits in LDS, every x load applies it.
     // (not in PAIR mode: its register budget is full, the plan keeps film_apply there)
-    float* ab_s = reinterpret_cast<float*>(WLDS ? Wsl + (size_t)256 * SA_WROW : Wsh);     // behind the last array in use
+    float* ab_s = reinterpret_cast<float*>(WLDS ? Wsl + (size_t)256 * SA_WROW : Wsh);     // the FiLM row (see the layout)
     const bool fold = !PAIR && a.ab != nullptr;
     if (fold) {
         if (tid < 2 * SA_C / 4)
@@ -482,10 +497,10 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     // ---- feed-forward: LN -> W1 -> GELU -> W2 -> + av ----
     if (WLDS) {                                     // phase B of the staged weights (every wave is past the out-proj reads)
         __syncthreads();
-        sa_stage_rows(Wsh, 0, a.w1_h, 64, tid, blockDim.x);
-        sa_stage_rows(Wsl, 0, a.w1_l, 64, tid, blockDim.x);
-        sa_stage_rows(Wsh, 64, a.w2_h, 64, tid, blockDim.x);
-        sa_stage_rows(Wsl, 64, a.w2_l, 64, tid, blockDim.x);
+        sa_stage_rows(Fsh, 0, a.w1_h, 64, tid, blockDim.x);
+        sa_stage_rows(Fsl, 0, a.w1_l, 64, tid, blockDim.x);
+        sa_stage_rows(Fsh, 64, a.w2_h, 64, tid, blockDim.x);
+        sa_stage_rows(Fsl, 64, a.w2_l, 64, tid, blockDim.x);
         __syncthreads();
     }
     SAF_STAMP()
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
-        f[T] = WLDS ? sa_gemm_tile_lds(Wsh, Wsl, 32 * T, li, kh, bh, bl, f[T]) : sa_gemm_tile(a.w1_h, a.w1_l, 32 * T, li, kh, bh, bl, f[T]);
+        f[T] = WLDS ? sa_gemm_tile_lds(Fsh, Fsl, 32 * T, li, kh, bh, bl, f[T]) : sa_gemm_tile(a.w1_h, a.w1_l, 32 * T, li, kh, bh, bl, f[T]);
         sa_bias(f[T], a.b1, T, kh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[T][r] = gelu_erf(f[T][r]);
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[T][r] = 0.f;
-        f[T] = WLDS ? sa_gemm_tile_lds(Wsh, Wsl, 64 + 32 * T, li, kh, bh, bl, f[T]) : sa_gemm_tile(a.w2_h, a.w2_l, 32 * T, li, kh, bh, bl, f[T]);
+        f[T] = WLDS ? sa_gemm_tile_lds(Fsh, Fsl, 64 + 32 * T, li, kh, bh, bl, f[T]) : sa_gemm_tile(a.w2_h, a.w2_l, 32 * T, li, kh, bh, bl, f[T]);
         sa_bias(f[T], a.b2, T, kh);
     }
 #ifdef SA_ABLATE_NOFF
@@ -531,6 +546,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             }
     }
     SAF_STAMP()
+    }   // trajectories of this workgroup
 }
 
 #ifdef SPDM_DIAG_SAF
@@ -546,7 +562,7 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
                              const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s) {
     if (!sa_fused_supported(L, SA_C) || B <= 0) return hipErrorInvalidValue;
     SaFusedArgs a{};
-    a.x = x; a.out = out; a.L = L;
+    a.x = x; a.out = out; a.L = L; a.nb = B;
     a.ln1_g = ln1_g; a.ln1_b = ln1_b; a.ln2_g = ln2_g; a.ln2_b = ln2_b;
     a.wqkv_h = (const _Float16*)w_hl[0]; a.wqkv_l = (const _Float16*)w_hl[1];
     a.wo_h = (const _Float16*)w_hl[2]; a.wo_l = (const _Float16*)w_hl[3];
@@ -558,7 +574,8 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     const int nwave = pair ? 8 : (L + 31) / 32;
     const int Lp = pair ? 512 : nwave * 32;
     const bool wlds = !pair && (nwave >= 4) && !(sw & SW_SA_NO_WLDS);      // long sequences: weights staged in LDS
-    const size_t lds = ((size_t)2 * Lp * SA_KROW + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16) +
+    const size_t kreg = (size_t)2 * Lp * SA_KROW, freg = (size_t)2 * 128 * SA_WROW;           // halfs: K hi + lo; ff1 / ff2 hi + lo
+    const size_t lds = ((wlds ? std::max(kreg, freg) : kreg) + (size_t)2 * 32 * (Lp + 8) + (wlds ? (size_t)2 * 256 * SA_WROW : 0)) * sizeof(_Float16) +
                        2 * SA_C * sizeof(float);                                               // + the FiLM-coefficient row
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool full = (L % 32 == 0);
@@ -568,7 +585,17 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
                     : (wlds ? sa_fused64_kernel<false, true, false> : sa_fused64_kernel<false, false, false>);
     if (lds > 64 * 1024)
         if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(pair ? 2 * B : B), dim3(64 * nwave), lds, s, a);
+    int grid = pair ? 2 * B : B;
+    if (wlds) {                                    // persistent workgroups: one per CU (LDS-bound), each walks B / grid trajectories
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            ncu = n;
+        }
+        grid = std::min(B, ncu);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nwave), lds, s, a);
     return hipGetLastError();
 }
 
