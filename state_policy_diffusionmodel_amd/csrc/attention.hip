@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void attention_ds_kernel(const float* __restri
             s0 += q[k] * kv.x; s1 += q[k + 1] * kv.y; s2 += q[k + 2] * kv.z; s3 += q[k + 3] * kv.w;
         }
         float sc = (s0 + s1) + (s2 + s3);
-        sc += __shfl_xor(sc, 1, 64);              // the four feature slices of this query (fixed order: deterministic)
-        sc += __shfl_xor(sc, 2, 64);
+        // the four feature slices of this query (fixed order: deterministic): quad swaps by DPP -- the same additions as
+        // __shfl_xor 1 and 2, without two LDS-crossbar round trips on the per-key dependency chain of the online softmax
+        sc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sc), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+        sc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sc), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
         const float mn = fmaxf(m, sc);
         const float alpha = att_exp_neg(m - mn);
         const float p = att_exp_neg(sc - mn);
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             }
             mraw = fmaxf(mraw, sc[r]);
         }
-        mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+        mraw = max_xor32(mraw);
         const float m_new = fmaxf(m, mraw * SC);
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         const float off = 10.0f - m_new;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             }
         }
     }
-    lsum += __shfl_xor(lsum, 32, 64);
+    lsum = sum_xor32(lsum);
     const float inv = 1.0f / (lsum * 16.0f);             // lsum carries the x1024 of p; v scale 16
     if (q < L) {
         float* orow = out + ((size_t)b * L + q) * C + hd * D;

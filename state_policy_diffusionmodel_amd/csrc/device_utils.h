@@ -22,8 +22,45 @@ __device__ __forceinline__ void sample_mean_rstd(const StatsRef& st, int b, floa
     rstd = (float)(1.0 / sqrt(var + 1e-5));
 }
 
+// own + the value of lane ^ 32 (or ^ 16), in every lane, by gfx950's v_permlane32_swap / v_permlane16_swap: with both operands the
+// same register the two results hold {own, partner} in one order or the other, so their sum (or max) is the same in both lanes
+// and bit-identical to v + __shfl_xor(v, 32) -- a VALU operation instead of a round trip through the LDS crossbar (ds_bpermute).
+__device__ __forceinline__ float sum_xor32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float max_xor32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float sum_xor16(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ double sum_xor32_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double a = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[0] << 32) | (unsigned)rl[0]);
+    const double b = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[1] << 32) | (unsigned)rl[1]);
+    return a + b;
+}
+__device__ __forceinline__ double sum_xor16_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double a = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[0] << 32) | (unsigned)rl[0]);
+    const double b = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[1] << 32) | (unsigned)rl[1]);
+    return a + b;
+}
+
 // Sum of a double over the 64 lanes of a wave, every lane ends with the total: the four in-row steps move the two halves by
-// DPP (VALU only), rows are joined by two ds_bpermute steps.  Fixed order: deterministic.
+// DPP, rows are joined by v_permlane16_swap / v_permlane32_swap: VALU only.  Fixed order: deterministic.
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #define DPP_ADD64(ctrl_)                                                                                        \
     {                                                                                                           \
@@ -37,8 +74,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     DPP_ADD64(0x141)     // row_half_mirror
     DPP_ADD64(0x140)     // row_mirror
 #undef DPP_ADD64
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = sum_xor16_f64(v);
+    v = sum_xor32_f64(v);
     return v;
 }
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&
     for (int T = 0; T < 2; ++T)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += z[T][r];
-    s += __shfl_xor(s, 32, 64);
+    s = sum_xor32(s);
     const float mean = s * (1.0f / 64.0f);
     float q = 0.f;
 #pragma unroll
@@ -145,7 +145,7 @@ __device__ __forceinline__ void sa_layernorm(const s_f32x16 (&z)[2], s_f32x16 (&
             const float d = z[T][r] - mean;
             q += d * d;
         }
-    q += __shfl_xor(q, 32, 64);
+    q = sum_xor32(q);
     const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
     for (int T = 0; T < 2; ++T)
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
                     }
                     mraw = fmaxf(mraw, sc[r]);
                 }
-                mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+                mraw = max_xor32(mraw);                 // (v_permlane32_swap: no LDS round trip on the per-block chain)
                 const float m_new = fmaxf(m, mraw * SC);
                 // rescale only when some query of the wave saw a new maximum (after the first blocks it rarely moves): a
                 // wave-uniform branch that saves the exp2 and the 16 multiplies of the common case; alpha would be exactly 1

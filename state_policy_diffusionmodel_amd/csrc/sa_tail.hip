@@ -63,13 +63,12 @@ __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
 }
 // sum over the TPR consecutive lanes that hold one row (32: a half-wave; 64: the wave)
 // (the first four butterfly steps inside the DPP rows -- VALU only; 16 and 32 through ds_bpermute: a LayerNorm phase of
-//  8 row pieces x 2 sums x 5-6 bpermutes per thread was bound by the LDS crossbar)
+//  8 row pieces x 2 sums x 5-6 bpermutes per thread was bound by the LDS crossbar; the row joins by v_permlane*_swap)
 template <int TPR>
 __device__ __forceinline__ float trow_sum(float v) {
     static_assert(TPR == 32 || TPR == 64, "rows of 32 or 64 lanes");
-    v = row16_sum_dpp(v);
-#pragma unroll
-    for (int o = 16; o < TPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    v = sum_xor16(row16_sum_dpp(v));
+    if (TPR == 64) v = sum_xor32(v);
     return v;
 }
 
@@ -232,9 +231,11 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) part[i] = row16_sum_dpp(part[i]);
 #pragma unroll
-        for (int o = 16; o < TPR; o <<= 1)
+        for (int i = 0; i < NP; ++i) part[i] = sum_xor16(part[i]);
+        if (TPR == 64) {
 #pragma unroll
-            for (int i = 0; i < NP; ++i) part[i] += __shfl_xor(part[i], o, 64);
+            for (int i = 0; i < NP; ++i) part[i] = sum_xor32(part[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const float mean = part[i] * (1.0f / (float)C);
@@ -246,9 +247,11 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) part[i] = row16_sum_dpp(part[i]);
 #pragma unroll
-        for (int o = 16; o < TPR; o <<= 1)
+        for (int i = 0; i < NP; ++i) part[i] = sum_xor16(part[i]);
+        if (TPR == 64) {
 #pragma unroll
-            for (int i = 0; i < NP; ++i) part[i] += __shfl_xor(part[i], o, 64);
+            for (int i = 0; i < NP; ++i) part[i] = sum_xor32(part[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const float rstd = __builtin_amdgcn_rsqf(part[i] * (1.0f / (float)C) + 1e-5f);        // v_rsq_f32 (1 ulp)
@@ -345,13 +348,38 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
             v[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
         }
         if (a.ab != nullptr) tail_film_fold<C>(v, a.ab, a.L, m0, M, c16, srow0);
+        // (the NP row pieces go through the two cross-lane sums together, as in sa_tail_kernel)
+        float part[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = row16_sum_dpp(part[i]);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = sum_xor16(part[i]);
+        if (TPR == 64) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) part[i] = sum_xor32(part[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
+            const float mean = part[i] * (1.0f / (float)C);
             const tf32x4 t = v[i];
-            const float mean = trow_sum<TPR>((t.x + t.y) + (t.z + t.w)) * (1.0f / (float)C);
             const tf32x4 d = {t.x - mean, t.y - mean, t.z - mean, t.w - mean};
-            const float var = trow_sum<TPR>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / (float)C);
-            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+            v[i] = d;
+            part[i] = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = row16_sum_dpp(part[i]);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = sum_xor16(part[i]);
+        if (TPR == 64) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) part[i] = sum_xor32(part[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float rstd = __builtin_amdgcn_rsqf(part[i] * (1.0f / (float)C) + 1e-5f);
+            const tf32x4 d = v[i];
             v[i] = tf32x4{d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w};
         }
     }
