@@ -716,10 +716,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
                         d2 += (double)srow[(uc * WN + w2) * 2 + 1];
                     }
                     const int seg = whole ? NU : ups;
-                    for (int o = 1; o < seg; o <<= 1) {
-                        d1 += __shfl_xor(d1, o, 64);
-                        d2 += __shfl_xor(d2, o, 64);
-                    }
+                    d1 = seg_sum_f64(d1, seg);              // (the xor butterfly 1, 2, 4, ..., bit for bit; DPP + permlane swaps)
+                    d2 = seg_sum_f64(d2, seg);
                     const int row = t_lo + 4 * u;
                     if (u < NU && (u & (seg - 1)) == 0 && row < t_hi) {
                         const int b = row / HW;

@@ -79,6 +79,26 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+// Butterfly sum of a double inside aligned power-of-two lane segments of `seg` lanes (wave-uniform), steps 1, 2, 4, ... in that
+// order: bit-identical to `for (o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o)`, without the LDS crossbar.
+__device__ __forceinline__ double seg_sum_f64(double v, int seg) {
+#define DPP_ADD64(ctrl_)                                                                                        \
+    {                                                                                                           \
+        const unsigned long long u_ = __builtin_bit_cast(unsigned long long, v);                                \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u_, ctrl_, 0xf, 0xf, false);             \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u_ >> 32), ctrl_, 0xf, 0xf, false);     \
+        v += __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi_ << 32) | (unsigned long long)(unsigned)lo_); \
+    }
+    if (seg > 1) DPP_ADD64(0xB1)
+    if (seg > 2) DPP_ADD64(0x4E)
+    if (seg > 4) DPP_ADD64(0x141)
+    if (seg > 8) DPP_ADD64(0x140)
+#undef DPP_ADD64
+    if (seg > 16) v = sum_xor16_f64(v);
+    if (seg > 32) v = sum_xor32_f64(v);
+    return v;
+}
+
 // The same for a whole wave (all 64 lanes call it, all get the result).  The fine tilings of the small-grid kernels leave up to
 // ~130 partial slots per sample (16-row x 32-column tiles); one thread adding them one after the other was 3-6 us of a 9-15 us
 // launch at batch 1.  Few slots: lane order as above (same bits as the serial form); many: lane i adds slots i, i + 64, ...

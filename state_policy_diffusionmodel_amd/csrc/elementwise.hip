@@ -609,11 +609,8 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
         d1 += (double)s1;
         d2 += (double)s2;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        d1 += __shfl_xor(d1, o, 64);
-        d2 += __shfl_xor(d2, o, 64);
-    }
+    d1 = wave_sum_f64(d1);                          // (DPP + permlane swaps: fixed order, no LDS crossbar)
+    d2 = wave_sum_f64(d2);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d1; red[1][threadIdx.x >> 6] = d2; }
     __syncthreads();
     if (threadIdx.x == 0) {
