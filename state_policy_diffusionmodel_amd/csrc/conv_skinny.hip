@@ -1,5 +1,7 @@
-// conv_skinny.hip -- 3x3 / 3x1 convolution for a handful of rows (the closed-loop caller: run_predictions.py:140-175 calls
-// sample() at batch 1, so the coarse levels have M = B H_l W_l = 16 or 4 rows against K = 9 Cin up to 4608).
+// conv_skinny.hip -- 3x3 / 3x1 convolution for launches whose grid would not fill the chip: first written for a handful of rows
+// (the closed-loop caller: run_predictions.py:140-175 calls sample() at batch 1, so the coarse levels have M = B H_l W_l = 16 or
+// 4 rows against K = 9 Cin up to 4608), now every layer whose (rows / 16 | 32 | 64) x (N / 64) tiles stay within 256 workgroups
+// (conv_skinny_geometry below: all 31 convolutions at batch 1, the coarse levels up to batch 1024).
 //
 // Same math, operand formats and epilogue contract as conv_wide.hip / conv_gemm.hip (split-fp16 operands, hi*hi + hi*lo + lo*hi
 // into fp32, GroupNorm(1,C) -> GELU prologue applied at staging, GroupNorm partial sums as the epilogue; replaces
