@@ -267,7 +267,10 @@ __global__ __launch_bounds__(256) void upcat_kernel(const AffineSrc up, const Af
             o.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
             o.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
         } else {
-            o = apply_affine(af, *reinterpret_cast<const float4*>(skip.x + ((size_t)b * HWo + ro) * Cs + cl));
+            // (the last reader of the skip tensor: streamed past the caches)
+            typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+            const nt_f32x4 sv = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(skip.x + ((size_t)b * HWo + ro) * Cs + cl));
+            o = apply_affine(af, make_float4(sv.x, sv.y, sv.z, sv.w));
         }
         *reinterpret_cast<float4*>(dst + ((size_t)b * HWo + ro) * C + c4 * 4) = o;
     }
