@@ -33,8 +33,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 OBS_H, OBS_DIM = 10, 135
-TRAFFIC_FILE = os.path.join("profiles", "r02_roofline_traffic.json")       # rocprofv3 PMC passes of round 2 (tools/profile_sweep.sh)
-TRAFFIC_FALLBACK = os.path.join("profiles", "r01_roofline_traffic.json")
+TRAFFIC_GLOB = os.path.join("profiles", "r*_roofline_traffic*.json")      # rocprofv3 PMC passes (tools/pmc_traffic.py), one file per geometry
+
+
+def find_traffic(B, H, D, attention, kind):
+    """The committed PMC traffic summary whose geometry is this run's (latest round first); None if there is none."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, TRAFFIC_GLOB)), reverse=True):
+        try:
+            with open(path) as fh:
+                t = json.load(fh)
+        except Exception:
+            continue
+        c = t.get("config", {"batch": 4096, "horizon": 32, "state_dim": 3, "kind": "ddpm", "attention": True})
+        if (c.get("batch"), c.get("horizon"), c.get("state_dim")) == (B, H, D) and bool(c.get("attention", True)) == attention \
+                and "traffic_bytes_per_launch" in t:
+            t["_file"] = os.path.relpath(path, ROOT)
+            return t
+    return None
 
 
 def parse(argv=None):
@@ -55,12 +71,16 @@ def parse(argv=None):
     p.add_argument("--instrument-steps", type=int, default=2,
                    help="how many of the K timed steps carry per-launch HIP events (the rest replay as hipGraphs, the product's path); 0 = all")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-batch", type=int, default=64)
+    p.add_argument("--cpu-batch", type=int, default=None,
+                   help="batch of the CPU-oracle sample (default: the run's per-GPU batch, capped at 1024: SURVEY 8d asks for the target batch)")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="collective backend (gloo + --stub-engine: CPU rehearsal of the launcher and the timing protocol)")
     p.add_argument("--shared-device", action="store_true",
                    help="every rank uses cuda:0 (rehearsal of the N > 1 path with the real engine on a 1-GPU box; use with --backend gloo)")
+    p.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank exits 3 before the rendezvous
+    p.add_argument("--launch-timeout", type=float, default=1500.0,
+                   help="seconds the self-launcher waits for its ranks before it terminates them (N > 1 without torchrun)")
     p.add_argument("--stub-engine", action="store_true",
                    help="replace the HIP engine by a sleep (tests/test_bench_launcher.py only; the line says so)")
     return p.parse_args(argv)
@@ -100,7 +120,7 @@ def cpu_baseline(args, sd, cond_dim):
     from oracle.unet_film_ref import unet_film_forward
     cores = host_cores()
     torch.set_num_threads(cores)
-    B, H, D = args.cpu_batch, args.horizon, args.state_dim
+    B, H, D = (args.cpu_batch or min(args.batch, 1024)), args.horizon, args.state_dim
     g = torch.Generator().manual_seed(1)
     cond = torch.randn(B, 1, OBS_H, cond_dim // OBS_H, generator=g)
     x = torch.rand(B, 1, H, D, generator=g)
@@ -121,7 +141,7 @@ def cpu_baseline(args, sd, cond_dim):
         x = one_step(x, args.train_steps - 2 - n)
         n += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or n >= 400:
+        if (el >= args.cpu_seconds and n >= 3) or n >= 400 or el >= 4 * args.cpu_seconds:
             break
     return {"value": B * n / el, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement), batch {B}, {n} full denoise steps "
@@ -146,15 +166,44 @@ def self_launch(args) -> int:
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        # The host driver of this pool only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's intra-node
+        # transport fails with `hipIpcGetMemHandle: invalid argument`.  A caller's own setting wins.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(rc != 0 for rc in rcs):
-        print(f"[bench] ranks exited with {rcs}", file=sys.stderr)
+    # rank 0's stdout is drained by a thread so that polling every child never blocks on a full pipe
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + args.launch_timeout
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs) or time.monotonic() > deadline:
+            failed = True          # one rank died (or the job overran): the others would sit in the rendezvous / a barrier
+            break
+        time.sleep(0.05)
+    if failed:
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                p.terminate()
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                try:
+                    rcs[i] = p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    rcs[i] = p.wait()
+        why = "timed out" if all(rc in (None, 0) or rc < 0 for rc in rcs) and time.monotonic() > deadline else "a rank failed"
+        print(f"[bench] {why}; ranks exited with {rcs}", file=sys.stderr)
         return 1
-    for ln in out0.splitlines():           # rank 0's JSON line to stdout; anything a library printed goes to stderr
+    reader.join(timeout=10)
+    for ln in "".join(out0).splitlines():  # rank 0's JSON line to stdout; anything a library printed goes to stderr
         (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     return 0
@@ -188,12 +237,14 @@ class StubEngine:
         pass
 
 
-def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, profile, sync, instr=2):
-    """W untimed + exactly K timed denoise steps of one workload on this rank's shard, all-gather included; returns
-    (max-over-ranks seconds, conv launches, conv ms, conv flops, graph-replay seconds or None, final iterates)."""
+def timed_run(eng, dist, world, dev, cond, x_T, inpaint, W, K, T, profile, sync, instr=2):
+    """W untimed + exactly K timed denoise steps of one workload, all-gather included.  cond / x_T / inpaint are the GLOBAL
+    batch (the same tensors on every rank); the product's own sharding driver (distributed.ShardedSampler) slices this
+    rank's contiguous shard, runs the loop on it and all-gathers the iterates.  Returns (max-over-ranks seconds, conv
+    launches, conv ms, conv flops, graph-replay seconds or None, final iterates of ALL ranks, instrumented steps)."""
     import torch
-    B = x_T.shape[0]
-    gathered = torch.empty((world * B,) + tuple(x_T.shape[1:]), device=dev) if world > 1 else None
+    from state_policy_diffusionmodel_amd.distributed import ShardedSampler
+    ss = ShardedSampler(eng)
 
     def barrier():
         sync()
@@ -201,10 +252,10 @@ def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, p
             dist.barrier()
             sync()
 
-    eng.sample_begin(cond, x_T, noise=None, inpaint=inpaint, seed=7, sample_offset=rank_offset)
-    eng.sample_run(0, W)                                   # untimed warm-up steps
+    ss.begin(cond, x_T, noise=None, inpaint=inpaint, seed=7)
+    ss.run(0, W)                                           # untimed warm-up steps
     if world > 1:
-        dist.all_gather_into_tensor(gathered, x_T.contiguous())   # untimed: the backend sets its channels up on the first call of a kind
+        ss.result()                                        # untimed: the backend sets its channels up on the first call of a kind
     # The timed region is EXACTLY K denoise steps: the first K - P the way the product runs them (spdm_sample_run replays each
     # step as a hipGraph), the last P with HIP events around every run of consecutive conv3x3 launches on the launch stream --
     # what `roofline` is measured from (events cannot sit inside a replayed graph, and instrumenting all K steps with plain
@@ -217,13 +268,11 @@ def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, p
     barrier()
     t0 = time.perf_counter()
     if K - P > 0:
-        eng.sample_run(W, W + K - P)
+        ss.run(W, W + K - P)
     if profile:
         eng.profile(True)
-    eng.sample_run(W + K - P, W + K)
-    out = eng.sample_result()
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, out.contiguous())   # RCCL over xGMI, closes the timed region
+    ss.run(W + K - P, W + K)
+    out = ss.result()                                      # N > 1: one all-gather (RCCL over xGMI) closes the timed region
     barrier()
     el = time.perf_counter() - t0
     launches = conv_ms = conv_flops = 0
@@ -236,7 +285,7 @@ def timed_run(eng, dist, world, dev, cond, x_T, inpaint, rank_offset, W, K, T, p
     if profile and W + 2 * K <= T:
         barrier()
         t1 = time.perf_counter()
-        eng.sample_run(W + K, W + 2 * K)
+        ss.run(W + K, W + 2 * K)
         barrier()
         el_graph = time.perf_counter() - t1
     tmax = torch.tensor([el, el_graph if el_graph is not None else 0.0], device=dev, dtype=torch.float64)
@@ -262,6 +311,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
     stub = args.stub_engine
+    if stub and rank == args.stub_fail_rank:
+        raise SystemExit(3)
     if stub:
         dev = torch.device("cpu")
         sync = lambda: None                                                     # noqa: E731
@@ -305,23 +356,26 @@ def main():
         sched.set_timesteps(T)
         eng.set_scheduler(sched)
 
-    def inputs(B, first):
-        # synthetic inputs of this rank's shard; global trajectory index = first + b (seeded per shard)
-        g = torch.Generator().manual_seed(1000 + first)
-        cond = torch.randn(B, 1, OBS_H, OBS_DIM, generator=g).to(dev)
-        x_T = torch.rand(B, 1, H, D, generator=g).to(dev)
-        inpaint = (torch.rand(B, 1, 1, D, generator=g) * 2 - 1).to(dev)
+    def inputs(Btot):
+        # synthetic GLOBAL inputs, identical on every rank (seeded); ShardedSampler takes this rank's rows
+        g = torch.Generator().manual_seed(1000)
+        cond = torch.randn(Btot, 1, OBS_H, OBS_DIM, generator=g).to(dev)
+        x_T = torch.rand(Btot, 1, H, D, generator=g).to(dev)
+        inpaint = (torch.rand(Btot, 1, 1, D, generator=g) * 2 - 1).to(dev)
         return cond, x_T, inpaint
 
     runs = {}
     modes = ["weak"] if world == 1 else (["strong", "weak"] if headline == "strong" else ["weak", "strong"])
     for mode in modes:
         B = Bw if mode == "weak" else Bs
-        cond, x_T, inpaint = inputs(B, rank * B)
+        cond, x_T, inpaint = inputs(world * B)
         el, launches, conv_ms, conv_flops, el_graph, out, instr_steps = timed_run(
-            eng, dist, world, dev, cond, x_T, inpaint, rank * B, W, K, T, profile=True, sync=sync, instr=args.instrument_steps)
+            eng, dist, world, dev, cond, x_T, inpaint, W, K, T, profile=True, sync=sync, instr=args.instrument_steps)
+        if tuple(out.shape) != (world * B, 1, H, D):
+            raise SystemExit(f"bench: gathered iterates have shape {tuple(out.shape)}, expected {(world * B, 1, H, D)}")
         if not bool(torch.isfinite(out).all()):
             raise SystemExit("bench: non-finite iterate")
+        del cond, x_T, inpaint, out
         runs[mode] = dict(B=B, el=el, launches=launches, conv_ms=conv_ms, conv_flops=conv_flops, el_graph=el_graph,
                           instr_steps=instr_steps)
 
@@ -384,19 +438,11 @@ def roofline(args, r, split, B, H, D, el, K):
               "3x3 implicit GEMM, split-fp16 operands, fp32 accumulate" if split
               else "conv_gemm_kernel (3x3 implicit GEMM; v_mfma_f32_32x32x2_f32)")
     traffic = hbm_step = src = None
-    for cand in (TRAFFIC_FILE, TRAFFIC_FALLBACK):
-        try:
-            with open(os.path.join(ROOT, cand)) as fh:
-                t = json.load(fh)
-        except Exception:
-            continue
-        cfgp = t.get("config", {"batch": 4096, "horizon": 32, "state_dim": 3, "kind": "ddpm", "attention": True})
-        if (cfgp.get("batch"), cfgp.get("horizon"), cfgp.get("state_dim")) == (B, H, D) and \
-                bool(cfgp.get("attention", True)) == (not args.no_attention):
-            traffic = float(t["traffic_bytes_per_launch"])
-            hbm_step = t.get("hbm_bytes_per_step")
-            src = f"static: {cand} (rocprofv3 PMC passes of this geometry; not re-measured in this run)"
-        break
+    t = find_traffic(B, H, D, not args.no_attention, args.kind)
+    if t is not None:
+        traffic = float(t["traffic_bytes_per_launch"])
+        hbm_step = t.get("hbm_bytes_per_step")
+        src = f"static: {t['_file']} (rocprofv3 PMC passes of this geometry; not re-measured in this run)"
     out = {"bound": "mfma", "kernel": kernel,
            "achieved": algo, "peak": peak, "unit": "TFLOP/s", "frac": algo / peak,
            "algorithmic_frac": algo / peak,

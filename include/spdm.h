@@ -159,6 +159,12 @@ int  spdm_sample_begin(spdm_handle* h, int32_t B, const float* d_cond,
 int  spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_end, void* stream);
 int  spdm_sample_result(spdm_handle* h, float* d_out, void* stream);
 
+/* How many times this handle has captured its denoise step into a hipGraph.  spdm_sample_run replays one captured step
+ * for every iteration; the capture is keyed by the session's SHAPE (batch, inpaint horizon, scheduler, switches), not by
+ * the addresses of the caller's buffers or the seed -- so the closed-loop caller (run_predictions.py:151-156: one
+ * model.sample() per control period, fresh tensors every time) captures once and replays ever after. */
+int64_t spdm_graph_captures(const spdm_handle* h);
+
 /* Introspection for tests: copy a named intermediate of the LAST
  * spdm_unet_forward (handle created with SPDM_FLAG_DEBUG_KEEP) to d_out in
  * channels-last (B, H_l*W_l, C) order; shape_out = {B, H_l, W_l, C}.
@@ -178,7 +184,8 @@ int32_t spdm_demoted_tensors(const spdm_handle* h);
 int  spdm_nonfinite(spdm_handle* h, int32_t* flag_out, void* stream);
 
 /* Flip one kernel-selection switch ("SPDM_NO_GRAPH", "SPDM_NO_WIDE", ... -- the names the environment is read for,
- * ONCE, at spdm_create) on a live handle.  Test / tuning hook: the product path never calls it. */
+ * ONCE, at spdm_create) on a live handle.  Test / tuning hook: the product path never calls it.  The workspace is
+ * re-planned for the new kernel selection (the unfused fallbacks need more scratch) and grown if it has to be. */
 int  spdm_set_switch(spdm_handle* h, const char* name, int32_t on);
 
 /* 1 if the handle's contractions run on the split-fp16 MFMA path, 0 on the exact fp32 MFMA path. */

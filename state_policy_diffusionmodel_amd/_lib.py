@@ -41,6 +41,7 @@ SYMBOLS = {
                                     c_uint64, c_uint64, c_void_p, c_void_p]),
     "spdm_sample_run": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "spdm_sample_result": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "spdm_graph_captures": (c_int64, [c_void_p]),
     "spdm_debug_tensor": (c_int32, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_int32 * 4)]),
     "spdm_uses_split_precision": (c_int32, [c_void_p]),
     "spdm_demoted_tensors": (c_int32, [c_void_p]),

@@ -828,7 +828,11 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
         if (wide128 && mt * nt128 < target) g.n_tile = 128, g.n_tiles = nt128;
         const long long tiles = mt * g.n_tiles;
         if (tiles < target) {
-            const int unit = (g.n_tile == 128 && wide128) ? 2 : 1;        // chunks per split step (the wide kernel walks taps in pairs)
+            // chunks per split step: a 128 x 128 tiling that conv_wide.hip takes (conv_wide_supported: rows per sample a
+            // multiple of 4, K a multiple of 64) walks its chunks in PAIRS -- kc0 = 2 (ks (K / 64) / ksplit) -- so splitting
+            // finer than K / 64 would give some workgroups an empty chunk range (an all-zero slab and a wasted combine pass)
+            const bool pairs = g.n_tile == 128 && (HW & 3) == 0 && K % 64 == 0 && !(sw & (SW_NO_WIDE | SW_NO_WIDE128));
+            const int unit = pairs ? 2 : 1;
             int S = (int)std::min<long long>(nchunks / unit, (target + tiles - 1) / tiles);
             while (S > 1 && (size_t)S * M * N * sizeof(float) > SPLITK_WORKSPACE_BYTES) --S;
             if (S > 1) g.ksplit = S;

@@ -537,13 +537,21 @@ __global__ __launch_bounds__(256) void out_step_kernel(const StepArgs a) {
     const int i = *a.step_dev;
     const float* c = a.coef + (size_t)i * 6;
     const float x = a.x[e];
+    const float* inpaint = a.inpaint;
+    const float* noise = a.noise;
+    float* history = a.history;
+    if (a.ptrs_dev != nullptr) {           // uniform (scalar) loads of the session's buffers
+        inpaint = static_cast<const float*>(a.ptrs_dev[0]);
+        noise = static_cast<const float*>(a.ptrs_dev[1]);
+        history = const_cast<float*>(static_cast<const float*>(a.ptrs_dev[2]));
+    }
     const float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(c[0], eps)), c[1]);
     float prev;
     if (a.kind == 0) {   // DDPM
         prev = __fadd_rn(__fmul_rn(c[2], x0), __fmul_rn(c[3], x));
         if (c[5] != 0.f) {
-            const float z = (a.noise != nullptr)
-                                ? a.noise[((size_t)i * a.B + b) * HD + he]
+            const float z = (noise != nullptr)
+                                ? noise[((size_t)i * a.B + b) * HD + he]
                                 : philox_normal(a.rng_dev[0], (unsigned)(a.rng_dev[1] + (unsigned long long)b),
                                                 (unsigned)i, (unsigned)he);
             prev = __fadd_rn(prev, __fmul_rn(c[5], z));
@@ -551,12 +559,12 @@ __global__ __launch_bounds__(256) void out_step_kernel(const StepArgs a) {
     } else {             // DDIM, eta = 0
         prev = __fadd_rn(__fmul_rn(c[2], x0), __fmul_rn(c[4], eps));
     }
-    if (h0 < a.inp_h && a.inpaint != nullptr)
-        prev = a.inpaint[(a.inpaint_per_sample ? (size_t)b * a.inp_h * a.D : 0) + (size_t)h0 * a.D + d];
+    if (h0 < a.inp_h && inpaint != nullptr)
+        prev = inpaint[(a.inpaint_per_sample ? (size_t)b * a.inp_h * a.D : 0) + (size_t)h0 * a.D + d];
     a.x[e] = prev;
     // overflow guard of the split-precision contractions (|activation| < 4094): surfaced by spdm_sample_nonfinite
     if (!(fabsf(prev) <= 3.0e38f)) *a.flag_dev = 1;
-    if (a.history != nullptr) a.history[((size_t)(i + 1) * a.B + b) * HD + he] = prev;
+    if (history != nullptr) history[((size_t)(i + 1) * a.B + b) * HD + he] = prev;
 }
 
 hipError_t launch_out_step(const StepArgs& a, hipStream_t s) {

@@ -202,6 +202,10 @@ struct StepArgs {
     int* flag_dev;                // device word, set to 1 when an updated iterate (or eps) is not finite
     const float* inpaint; int inp_h; int inpaint_per_sample;
     float* history;               // (n_steps+1, B, H0, D) or null
+    // Sampling loop: the three caller-owned buffers above are read from this device block {inpaint, noise, history} instead
+    // (written by spdm_sample_begin), so the launch arguments -- and with them the captured step graph -- do not depend on
+    // where a caller's tensors happen to live.  Null: the fields above are used as given (spdm_unet_forward).
+    const void* const* ptrs_dev;
     int B, H0, D, Hp, Wp, lh, lw;
 };
 hipError_t launch_out_step(const StepArgs& a, hipStream_t s);

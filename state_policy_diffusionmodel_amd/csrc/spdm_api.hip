@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -152,6 +153,7 @@ struct spdm_handle {
     int* d_t = nullptr;                   // [max_batch] timestep(s) of the current evaluation
     int* d_step = nullptr;                // [0] loop iteration, [2] non-finite flag (set by out_step_kernel)
     unsigned long long* d_rng = nullptr;  // {seed, first global trajectory index} of the device noise stream
+    const void** d_ptrs = nullptr;        // {inpaint, noise, history} of the session: read by out_step_kernel (StepArgs::ptrs_dev)
     float* d_condm = nullptr;             // Mish(cond), K padded
     float* d_film[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* d_x = nullptr;                 // current iterate (B,H0,D)
@@ -173,16 +175,17 @@ struct spdm_handle {
     // hipGraph of one denoise step (advance -> U-Net -> scheduler update), replayed by spdm_sample_run
     struct StepGraphKey {
         int B = 0, inp_h = 0, per_sample = 0, have_film = 0, sched_kind = 0, n_steps = 0;
-        const void *inpaint = nullptr, *noise = nullptr, *history = nullptr;
         unsigned env = 0;                 // the handle's kernel-selection switches when the step was captured
-        // (seed and trajectory offset are NOT part of the key: out_step_kernel reads them from d_rng, so a fresh seed per
-        //  sample() call replays the same graph)
+        // NOT part of the key: seed and trajectory offset (out_step_kernel reads them from d_rng) and the ADDRESSES of the
+        // caller's inpaint / noise / history buffers (read from d_ptrs) -- a fresh seed, or freshly allocated tensors of the
+        // same shapes, replay the same graph.  Presence or absence of a buffer needs no entry either: the kernel tests the
+        // pointer it loads.
         bool operator==(const StepGraphKey& o) const {
             return env == o.env && B == o.B && inp_h == o.inp_h && per_sample == o.per_sample && have_film == o.have_film &&
-                   sched_kind == o.sched_kind && n_steps == o.n_steps && inpaint == o.inpaint && noise == o.noise &&
-                   history == o.history;
+                   sched_kind == o.sched_kind && n_steps == o.n_steps;
         }
     } graph_key;
+    long long graph_captures = 0;         // step graphs built so far (spdm_graph_captures)
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_exec = nullptr;
     hipStream_t gstream = nullptr;        // blocking stream the loop runs on when the caller passes the NULL stream
@@ -341,6 +344,7 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
         if ((rc = dev_alloc(h, (void**)&h->d_t, sizeof(int) * mb))) break;
         if ((rc = dev_alloc(h, (void**)&h->d_step, sizeof(int) * 4))) break;
         if ((rc = dev_alloc(h, (void**)&h->d_rng, sizeof(unsigned long long) * 2))) break;
+        if ((rc = dev_alloc(h, (void**)&h->d_ptrs, sizeof(void*) * 4))) break;
         if (hipMemset(h->d_step, 0, sizeof(int) * 4) != hipSuccess) { rc = fail(SPDM_ERR_HIP, "memset failed"); break; }
         if ((rc = dev_alloc(h, (void**)&h->d_condm, sizeof(float) * (size_t)mb * h->film_kp))) break;
         static const int film_c[6] = {128, 256, 256, 128, 64, 64};
@@ -392,6 +396,8 @@ struct Loader {
     size_t n;
     std::map<std::string, const spdm_tensor_index*> idx;
     int err = SPDM_OK;
+    std::set<std::string> demoted_names;   // tensors outside the split format's range (counted once each, however many copies they lose)
+    void demote(const std::string& name) { demoted_names.insert(name); if (h) h->demoted = (int)demoted_names.size(); }
     const float* find(const std::string& name, std::initializer_list<int> shape) {
         auto it = idx.find(name);
         if (it == idx.end()) { err = fail(SPDM_ERR_MISSING, "tensor '%s' not in the index", name.c_str()); return nullptr; }
@@ -428,9 +434,9 @@ struct Loader {
         }
         return out;
     }
-    float* upload_split(const std::vector<float>& v, size_t K) {
+    float* upload_split(const std::vector<float>& v, size_t K, const std::string& name) {
         if (K % 32 != 0) { err = fail(SPDM_ERR_INVALID, "split weights need K %% 32 == 0"); return nullptr; }
-        if (!split_range_ok(v)) { if (h) ++h->demoted; return nullptr; }
+        if (!split_range_ok(v)) { demote(name); return nullptr; }
         return upload(split_format(v));
     }
     float* upload(const std::vector<float>& v) {
@@ -456,7 +462,7 @@ struct Loader {
                     v[((size_t)t * cout + o) * cin + i] = src[(((size_t)o * cin + i) * 3 + kh) * 3 + kw];
         }
         c.w = upload(v);
-        c.ws = (cin % 32 == 0) ? upload_split(v, cin) : nullptr;
+        c.ws = (cin % 32 == 0) ? upload_split(v, cin, name) : nullptr;
         if (c.ws && cout % 64 == 0) c.wf = upload(frag_order_weights(split_format(v), taps, cout, cin));
         c.taps = taps; c.cin = cin; c.cout = cout;
         return c;
@@ -473,7 +479,7 @@ struct Loader {
         std::vector<float> v((size_t)out * in_pad, 0.f);
         for (int o = 0; o < out; ++o) memcpy(&v[(size_t)o * in_pad], w + (size_t)o * in, sizeof(float) * in);
         l.w = upload(v);
-        l.ws = (in_pad % 32 == 0) ? upload_split(v, in_pad) : nullptr;
+        l.ws = (in_pad % 32 == 0) ? upload_split(v, in_pad, wname) : nullptr;
         l.b = vec(bname, out);
         l.in = in_pad; l.out = out;
         return l;
@@ -503,7 +509,7 @@ struct Loader {
         static const int perm16[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
         const float* w = find(wname, {out, 64});
         if (!w) return;
-        if (!split_range_ok(std::vector<float>(w, w + (size_t)out * 64))) { ++h->demoted; return; }   // block falls back to the GEMM chain
+        if (!split_range_ok(std::vector<float>(w, w + (size_t)out * 64))) { demote(wname); return; }   // block falls back to the GEMM chain
         std::vector<_Float16> hi((size_t)out * 64), lo((size_t)out * 64);
         for (int o = 0; o < out; ++o)
             for (int g = 0; g < 4; ++g)
@@ -540,7 +546,7 @@ struct Loader {
     float* linear_frag(const std::string& wname, int out, int in) {
         const float* w = find(wname, {out, in});
         if (!w) return nullptr;
-        if (!split_range_ok(std::vector<float>(w, w + (size_t)out * in))) { ++h->demoted; return nullptr; }
+        if (!split_range_ok(std::vector<float>(w, w + (size_t)out * in))) { demote(wname); return nullptr; }
         return upload(frag_order_weights(split_format(std::vector<float>(w, w + (size_t)out * in)), 1, out, in));
     }
     AttnW attn(const std::string& p, int C) {
@@ -572,6 +578,30 @@ struct Loader {
         return a;
     }
 };
+
+// dry run of the plan at max_batch with the handle's current kernel selection; grows the slab if this plan needs more
+static int replan_arena(spdm_handle* h) {
+    (void)hipDeviceSynchronize();         // nothing may still be running in the slab about to be re-planned
+    const bool keep = h->arena.keep;
+    h->arena.dry = true;
+    h->arena.peak = 0;
+    h->arena.reset();
+    Tensor feat;
+    const int rc = plan_forward(h, h->cfg.max_batch, true, nullptr, &feat);
+    h->arena.dry = false;
+    h->arena.keep = keep;
+    if (rc != SPDM_OK) return rc;
+    if (align_up(h->arena.peak, 4096) > h->arena.cap) {
+        char* nb = nullptr;
+        const size_t cap = align_up(h->arena.peak, 4096);
+        hipError_t e = hipMalloc((void**)&nb, cap);
+        if (e != hipSuccess) return fail(SPDM_ERR_NOMEM, "workspace of %zu bytes: %s", cap, hipGetErrorString(e));
+        h->owned.push_back(nb);        // (the smaller slab stays owned until destroy)
+        h->arena.base = nb;
+        h->arena.cap = cap;
+    }
+    return SPDM_OK;
+}
 
 extern "C" int spdm_load_weights(spdm_handle* h, const float* blob, size_t n, const spdm_tensor_index* index,
                                  int32_t n_index) {
@@ -632,22 +662,7 @@ extern "C" int spdm_load_weights(spdm_handle* h, const float* blob, size_t n, co
     if (h->demoted > 0) {
         // Some layers left the kernels the workspace was sized for (create() planned by shape only): plan again with the
         // weights known and grow the slab if this plan needs more.
-        h->arena.dry = true;
-        h->arena.peak = 0;
-        h->arena.reset();
-        Tensor feat;
-        const int rc = plan_forward(h, h->cfg.max_batch, true, nullptr, &feat);
-        h->arena.dry = false;
-        if (rc != SPDM_OK) return rc;
-        if (align_up(h->arena.peak, 4096) > h->arena.cap) {
-            char* nb = nullptr;
-            const size_t cap = align_up(h->arena.peak, 4096);
-            hipError_t e = hipMalloc((void**)&nb, cap);
-            if (e != hipSuccess) return fail(SPDM_ERR_NOMEM, "workspace of %zu bytes: %s", cap, hipGetErrorString(e));
-            h->owned.push_back(nb);        // (the smaller slab stays owned until destroy)
-            h->arena.base = nb;
-            h->arena.cap = cap;
-        }
+        SPDM_TRY(replan_arena(h));
     }
     return SPDM_OK;
 }
@@ -661,7 +676,8 @@ extern "C" int spdm_set_switch(spdm_handle* h, const char* name, int32_t on) {
     for (int i = 0; i < n; ++i)
         if (strcmp(t[i].env, name) == 0) {
             h->sw = on ? (h->sw | t[i].bit) : (h->sw & ~t[i].bit);
-            return SPDM_OK;
+            HIP_TRY(hipSetDevice(h->cfg.device));
+            return replan_arena(h);      // the arena was sized for the previous selection (the unfused fallbacks allocate more)
         }
     return fail(SPDM_ERR_INVALID, "unknown switch '%s'", name);
 }
@@ -1133,6 +1149,7 @@ static StepArgs step_args(spdm_handle* h, int B, const Tensor& feat) {
     a.noise = h->s_noise; a.rng_dev = h->d_rng; a.flag_dev = h->d_step + 2;
     a.inpaint = h->s_inpaint; a.inp_h = h->s_inp_h; a.inpaint_per_sample = h->s_inp_per_sample;
     a.history = h->s_history;
+    a.ptrs_dev = h->d_ptrs;
     a.B = B; a.H0 = h->cfg.horizon; a.D = h->cfg.state_dim; a.Hp = h->Hp; a.Wp = h->Wp; a.lh = h->lh; a.lw = h->lw;
     return a;
 }
@@ -1159,6 +1176,7 @@ extern "C" int spdm_unet_forward(spdm_handle* h, int32_t B, const float* d_x, co
     SPDM_TRY(plan_unet(c, h->d_x, d_cond != nullptr, &feat));
     StepArgs a = step_args(h, B, feat);
     a.eps_out = d_eps;
+    a.ptrs_dev = nullptr;
     HIP_TRY(launch_out_step(a, s));
     h->session = false;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
@@ -1190,6 +1208,8 @@ extern "C" int spdm_sample_begin(spdm_handle* h, int32_t B, const float* d_cond,
     {   // the noise stream's key lives on the device (read by out_step_kernel), so a new seed does not change the step's launches
         const unsigned long long rng[2] = {seed, sample_offset};
         HIP_TRY(hipMemcpyAsync(h->d_rng, rng, sizeof(rng), hipMemcpyHostToDevice, s));
+        const void* ptrs[4] = {h->s_inpaint, h->s_noise, h->s_history, nullptr};
+        HIP_TRY(hipMemcpyAsync(h->d_ptrs, ptrs, sizeof(ptrs), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(h->d_step + 2, 0, sizeof(int), s));
     }
     h->session = true;
@@ -1234,6 +1254,7 @@ static bool build_step_graph(spdm_handle* h, hipStream_t s) {
     }
     h->step_graph = g;
     h->step_exec = ge;
+    ++h->graph_captures;
     return true;
 }
 
@@ -1258,8 +1279,7 @@ extern "C" int spdm_sample_run(spdm_handle* h, int32_t step_begin, int32_t step_
         ++i;
         spdm_handle::StepGraphKey key;
         key.B = h->sB; key.inp_h = h->s_inp_h; key.per_sample = h->s_inp_per_sample; key.have_film = h->have_film ? 1 : 0;
-        key.sched_kind = h->sched_kind; key.n_steps = h->n_steps; key.inpaint = h->s_inpaint; key.noise = h->s_noise;
-        key.history = h->s_history;
+        key.sched_kind = h->sched_kind; key.n_steps = h->n_steps;
         key.env = h->sw;          // the captured launches depend on the kernel-selection switches (spdm_set_switch)
         if (!(h->step_exec && key == h->graph_key)) {
             if (build_step_graph(h, s)) h->graph_key = key;
@@ -1282,6 +1302,8 @@ extern "C" int spdm_sample_result(spdm_handle* h, float* d_out, void* stream) {
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return SPDM_OK;
 }
+
+extern "C" int64_t spdm_graph_captures(const spdm_handle* h) { return h ? h->graph_captures : 0; }
 
 extern "C" int spdm_nonfinite(spdm_handle* h, int32_t* flag_out, void* stream) {
     if (!h || !flag_out) return fail(SPDM_ERR_INVALID, "null argument");

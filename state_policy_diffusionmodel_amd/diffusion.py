@@ -165,7 +165,8 @@ class Diffusion_DDPM:
     # ==================== Sampling (models/diffusion_ddpm.py:223-277) ====================
     def sample(self, batch: Dict[str, torch.Tensor], option: Optional[str] = None, *,
                x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-               batched: bool = False, seed: Optional[int] = None, sample_offset: int = 0, every: int = 1):
+               batched: bool = False, seed: Optional[int] = None, sample_offset: int = 0, every: int = 1,
+               sharded: Optional[bool] = None, group=None):
         """``option``: None -> x_0 (B,1,H,D); 'sample_history' -> list of the N+1 iterates (the reference's form);
         'sample_history_stream' -> a generator of ``(i, x_i)`` host tensors handed out while the loop runs
         (``every``: stride in steps; SpdmEngine.sample_stream).
@@ -173,9 +174,26 @@ class Diffusion_DDPM:
         ``seed``: key of the device noise stream that replaces the ``torch.randn`` diffusers' DDPM ``step`` draws from
         the global generator on every step of every call.  None (default) draws a FRESH 62-bit seed per call from
         torch's global generator -- so, as with the reference, two calls give different trajectories and
-        ``torch.manual_seed`` makes a run reproducible.  Ignored when ``noise`` is supplied."""
+        ``torch.manual_seed`` makes a run reproducible.  Ignored when ``noise`` is supplied.
+
+        ``sharded`` (with ``batched=True``): every rank of the process group passes the SAME global batch; each runs its
+        contiguous slice of the trajectories on its own GPU (no communication inside the loop) and one all-gather -- RCCL
+        over xGMI on the "nccl" backend -- returns all B trajectories on every rank, rank-major, independent of the rank
+        count (distributed.ShardedSampler).  None (default): shard iff a process group with more than one rank is
+        initialised.  ``x_T`` and ``seed`` left at None are drawn on rank 0 and broadcast."""
+        from .distributed import ShardedSampler, shard_bounds, world_and_rank
+        world, rank = world_and_rank(group)
+        if sharded is None:
+            sharded = batched and world > 1
+        if sharded and not batched:
+            raise ValueError("sharded=True needs batched=True (the reference's B = 1 form has nothing to shard)")
+        if sharded and option == "sample_history_stream":
+            raise ValueError("option='sample_history_stream' hands out this process's iterates: not available with sharded=True")
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            seed_t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+            if sharded and world > 1:
+                seed_t = self._broadcast0(seed_t, group)
+            seed = int(seed_t.item())
         for key, tensor in batch.items():
             batch[key] = tensor.to(self.device)
         obs_cond = self.prepare_obs_cond_vectors(batch)                       # (B, obs_h, obs_dim)
@@ -188,20 +206,35 @@ class Diffusion_DDPM:
         H, D = self.pred_horizon + self.inpaint_horizon, self.prediction_dim
         if x_T is None:
             x_T = torch.rand(B, 1, H, D, device=self.device)                  # uniform, :252
+            if sharded and world > 1:
+                x_T = self._broadcast0(x_T, group)
         spec = _as_spec(self.noise_scheduler)
         spec.set_timesteps(self.noise_steps)                                  # :257/:268
-        eng = self._engine_for(B, H, D)
+        s0, s1 = shard_bounds(B, rank, world) if sharded else (0, B)
+        eng = self._engine_for(s1 - s0, H, D)
         eng.set_scheduler(spec)
+        ip = inpaint if self.inpaint_horizon > 0 else None
         if option == "sample_history_stream":
-            return eng.sample_stream(obs_cond, x_T, noise=noise, inpaint=inpaint if self.inpaint_horizon > 0 else None,
-                                     seed=seed, sample_offset=sample_offset, every=every)
+            return eng.sample_stream(obs_cond, x_T, noise=noise, inpaint=ip, seed=seed, sample_offset=sample_offset, every=every)
         want_hist = (option == "sample_history")
-        res = eng.sample(obs_cond, x_T, noise=noise, inpaint=inpaint if self.inpaint_horizon > 0 else None,
-                         seed=seed, sample_offset=sample_offset, history=want_hist)
+        if sharded:
+            if sample_offset:
+                raise ValueError("sample_offset is the shard's own bookkeeping when sharded=True")
+            res = ShardedSampler(eng, group).sample(obs_cond, x_T, noise=noise, inpaint=ip, seed=seed, history=want_hist)
+        else:
+            res = eng.sample(obs_cond, x_T, noise=noise, inpaint=ip, seed=seed, sample_offset=sample_offset, history=want_hist)
         if want_hist:
             _, hist = res
             return [hist[i] for i in range(hist.shape[0])]                    # list of N+1 (B,1,H,D), :256-265
         return res
+
+    def _broadcast0(self, t: torch.Tensor, group=None) -> torch.Tensor:
+        """rank 0's value of ``t`` on every rank (through the device for a backend that only moves device tensors)."""
+        import torch.distributed as dist
+        dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        buf = t.to(dev).contiguous()
+        dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return buf.to(t.device)
 
     # ==================== Helper functions (models/diffusion_ddpm.py:283-348) ====================
     def prepare_observation_batch(self, batch):

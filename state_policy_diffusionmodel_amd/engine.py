@@ -80,6 +80,11 @@ class SpdmEngine:
         """Weight tensors outside the split format's range (|w| >= 511), kept on the exact fp32 kernels."""
         return int(self.lib.spdm_demoted_tensors(self._h))
 
+    @property
+    def graph_captures(self) -> int:
+        """Step graphs captured so far: stays at 1 across sample() calls of one shape, whatever tensors they pass."""
+        return int(self.lib.spdm_graph_captures(self._h))
+
     def set_switch(self, name: str, on: bool = True) -> None:
         """Flip one kernel-selection switch (``SPDM_NO_GRAPH``, ``SPDM_NO_WIDE``, ...) on this handle.  The
         environment is read once, at construction; this is the test / tuning hook for a live engine."""

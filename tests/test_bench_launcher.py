@@ -58,3 +58,16 @@ def test_single_rank_stub_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip())
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+
+
+def test_launcher_terminates_the_other_ranks_when_one_dies():
+    """A rank that dies before the rendezvous must not leave rank 0 waiting for the backend's own timeout: the launcher
+    polls every child, terminates the rest on the first failure and exits non-zero."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--stub-engine", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--batch", "8", "--stub-fail-rank", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "a rank failed" in r.stderr
+    assert time.monotonic() - t0 < 60
+    assert not [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]     # never a line from a broken job

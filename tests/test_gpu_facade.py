@@ -136,3 +136,33 @@ def test_history_stream_yields_the_same_iterates_as_the_history_list():
         assert [i for i, _ in got] == want_idx
         for i, x in got:
             assert not x.is_cuda and torch.equal(x, hist[i].cpu())
+
+
+def test_closed_loop_calls_replay_one_captured_step():
+    """run_predictions.py:151-156 calls model.sample(batch) once per control period with freshly built tensors.  The
+    step graph is keyed by the session's shape, not by buffer addresses or the seed: the first call captures, every
+    later one replays -- with or without a history buffer, whatever the allocator hands out."""
+    from state_policy_diffusionmodel_amd.diffusion import Diffusion_DDPM
+    g = torch.Generator().manual_seed(3)
+    m = Diffusion_DDPM(noise_steps=8, obs_horizon=3, pred_horizon=14, observation_dim=11, prediction_dim=5,
+                       model="UNet_Film", inpaint_horizon=2, weight_seed=4)
+    keep = []
+    outs = []
+    for call in range(4):
+        obs = m.prepare_observation_batch(_batch(2, 5, g))
+        keep.append(torch.empty(1000 + 333 * call, device="cuda"))          # perturb the allocator between calls
+        x_T = torch.rand(1, 1, 16, 5, generator=g).cuda()
+        if call == 2:
+            hist = m.sample(dict(obs), option="sample_history", x_T=x_T, seed=call)
+            outs.append(hist[-1])
+        else:
+            outs.append(m.sample(dict(obs), x_T=x_T, seed=call))
+        assert m._engine.graph_captures == 1, call
+    # and the replayed graph really reads the NEW buffers: same inputs again give the same result, different ones differ
+    obs = m.prepare_observation_batch(_batch(2, 5, torch.Generator().manual_seed(77)))
+    x_T = torch.rand(1, 1, 16, 5, generator=torch.Generator().manual_seed(78)).cuda()
+    a = m.sample(dict(obs), x_T=x_T.clone(), seed=5)
+    b = m.sample(dict(obs), x_T=x_T.clone(), seed=5)
+    assert torch.equal(a, b) and not torch.equal(a, outs[0])
+    assert torch.equal(a[:, :, :2, :].cpu(), m.prepare_inpaint_vectors(obs)[0:1].unsqueeze(1).cpu())   # the NEW inpaint rows
+    assert m._engine.graph_captures == 1
