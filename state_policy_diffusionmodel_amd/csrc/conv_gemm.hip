@@ -849,6 +849,15 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
     return g;
 }
 
+// Which launches take a fused source (GemmArgs: PRO_POOL / PRO_UPCAT): the small-grid kernel (conv_skinny.hip) for both modes.
+// The plan (spdm_api.hip) asks before it decides whether to materialise the pooled / concatenated tensor.
+bool gemm_takes_fused_source(const GemmArgs& a) {
+    if (!(a.pro == PRO_POOL || a.pro == PRO_UPCAT) || !a.split || a.wgt_frag == nullptr || (a.sw & SW_NO_FUSED_SRC) || a.epi != EPI_STATS) return false;
+    if (a.pro == PRO_UPCAT && (a.up_C <= 0 || a.up_C >= a.K || a.up_C % CK != 0 || (a.H & 1) || (a.W & 1))) return false;
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    return g.skinny != 0;
+}
+
 // 2 x MACs the launch actually evaluates (the W = 2 zero-tap skipping runs 6 of the 9 taps)
 static bool uses_w2(const GemmArgs& a, const GemmGeom& g) {
     return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && !(a.sw & SW_NO_W2);
@@ -890,6 +899,7 @@ hipError_t launch_gemm(const GemmArgs& a0, hipStream_t s) {
     a.ksplit = 1;
     const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
     if (g.skinny) return launch_conv_skinny(a, g, s);
+    if (a.pro == PRO_POOL || a.pro == PRO_UPCAT) return hipErrorInvalidValue;      // (the plan asks gemm_takes_fused_source first)
     if (g.ksplit > 1) {
         if ((size_t)g.ksplit * a.M * a.N * sizeof(float) > SPLITK_WORKSPACE_BYTES || a.dst_ld != a.N) return hipErrorInvalidValue;
         a.ksplit = g.ksplit;

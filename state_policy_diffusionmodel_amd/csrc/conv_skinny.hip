@@ -54,11 +54,77 @@ __device__ int g_skinny_sel[2];
 #define SKINNY_STAMP(k_)
 #endif
 
+__device__ __forceinline__ k_f32x4 k_affine(k_f32x4 v, float mu, k_f32x4 sc, k_f32x4 be) {
+    return k_f32x4{(v.x - mu) * sc.x + be.x, (v.y - mu) * sc.y + be.y, (v.z - mu) * sc.z + be.z, (v.w - mu) * sc.w + be.w};
+}
+// One 16-byte piece (channels ch 32 + c4 4 ..) of input row m of a FUSED source (kernels.h, GemmArgs): the value the
+// materialising kernels (pool_kernel / upcat_kernel, elementwise.hip) would have written there -- same arithmetic, tap by tap.
+// smean / srstd: statistics of src per sample (index b - bh_first), smean1 / srstd1: of the skip tensor (PRO_UPCAT).
+template <int PRO>
+__device__ __forceinline__ k_f32x4 skinny_fused_piece(const GemmArgs& a, int m, int ch, int c4, int bh_first, const float* smean,
+                                                      const float* srstd, const float* smean1, const float* srstd1) {
+    const int HW = a.HW, W = a.W, H = a.H;
+    const int b = m / HW, pp = m - b * HW;
+    const int h = pp / W, w = pp - h * W;
+    const int c = ch * K_CK + c4 * 4;
+    if (PRO == PRO_UPCAT && c >= a.up_C) {          // skip half: one row of the same level
+        k_f32x4 v = *reinterpret_cast<const k_f32x4*>(a.skip + (size_t)m * a.skip_ld + (c - a.up_C));
+        if (a.skip_stats.p != nullptr) {
+            const float rs = srstd1[b - bh_first], mu = smean1[b - bh_first];
+            const k_f32x4 g4 = *reinterpret_cast<const k_f32x4*>(a.skip_gamma + (c - a.up_C));
+            const k_f32x4 b4 = *reinterpret_cast<const k_f32x4*>(a.skip_beta + (c - a.up_C));
+            v = k_affine(v, mu, k_f32x4{rs * g4.x, rs * g4.y, rs * g4.z, rs * g4.w}, b4);
+        }
+        return v;
+    }
+    const bool gn = a.pro_stats.p != nullptr;
+    float mu = 0.f;
+    k_f32x4 sc = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if (gn) {
+        const float rs = srstd[b - bh_first];
+        mu = smean[b - bh_first];
+        const k_f32x4 g4 = *reinterpret_cast<const k_f32x4*>(a.pro_gamma + c);
+        be = *reinterpret_cast<const k_f32x4*>(a.pro_beta + c);
+        sc = k_f32x4{rs * g4.x, rs * g4.y, rs * g4.z, rs * g4.w};
+    }
+    if (PRO == PRO_POOL) {                            // MaxPool2d(2) of the (2 H) x (2 W) map
+        const int Ws = 2 * W;
+        const float* base = a.src + ((size_t)b * 4 * HW + (size_t)(2 * h) * Ws + 2 * w) * a.src_ld + c;
+        k_f32x4 v00 = *reinterpret_cast<const k_f32x4*>(base);
+        k_f32x4 v01 = *reinterpret_cast<const k_f32x4*>(base + a.src_ld);
+        k_f32x4 v10 = *reinterpret_cast<const k_f32x4*>(base + (size_t)Ws * a.src_ld);
+        k_f32x4 v11 = *reinterpret_cast<const k_f32x4*>(base + (size_t)Ws * a.src_ld + a.src_ld);
+        if (gn) { v00 = k_affine(v00, mu, sc, be); v01 = k_affine(v01, mu, sc, be); v10 = k_affine(v10, mu, sc, be); v11 = k_affine(v11, mu, sc, be); }
+        return k_f32x4{fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)), fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y)),
+                       fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)), fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w))};
+    }
+    // bilinear x2, align_corners=True, of the (H / 2) x (W / 2) map (upcat_kernel's arithmetic)
+    const int Hin = H >> 1, Win = W >> 1;
+    const float sch = (H > 1) ? (float)(Hin - 1) / (float)(H - 1) : 0.f;
+    const float scw = (W > 1) ? (float)(Win - 1) / (float)(W - 1) : 0.f;
+    const float fh = sch * (float)h, fw = scw * (float)w;
+    const int h0 = (int)fh, w0 = (int)fw;
+    const int h1 = h0 + (h0 < Hin - 1 ? 1 : 0), w1 = w0 + (w0 < Win - 1 ? 1 : 0);
+    const float lh1 = fminf(fmaxf(fh - (float)h0, 0.f), 1.f), lw1 = fminf(fmaxf(fw - (float)w0, 0.f), 1.f);
+    const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+    const float* base = a.src + (size_t)b * Hin * Win * a.src_ld + c;
+    k_f32x4 v00 = *reinterpret_cast<const k_f32x4*>(base + ((size_t)h0 * Win + w0) * a.src_ld);
+    k_f32x4 v01 = *reinterpret_cast<const k_f32x4*>(base + ((size_t)h0 * Win + w1) * a.src_ld);
+    k_f32x4 v10 = *reinterpret_cast<const k_f32x4*>(base + ((size_t)h1 * Win + w0) * a.src_ld);
+    k_f32x4 v11 = *reinterpret_cast<const k_f32x4*>(base + ((size_t)h1 * Win + w1) * a.src_ld);
+    if (gn) { v00 = k_affine(v00, mu, sc, be); v01 = k_affine(v01, mu, sc, be); v10 = k_affine(v10, mu, sc, be); v11 = k_affine(v11, mu, sc, be); }
+    return k_f32x4{lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x),
+                   lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y),
+                   lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z),
+                   lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w)};
+}
+
 // RT row tiles of 16 (M_T = 16 RT), CT column tiles of 16 (N_T = 16 CT)
 template <int RT, int CT, int PRO>
 __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a, const int epi_slots, const int NS) {
     constexpr int M_T = RT * 16, N_T = CT * 16;
-    constexpr bool pro = (PRO != PRO_NONE), pro_gelu = (PRO == PRO_GN_GELU);
+    constexpr bool fused = (PRO == PRO_POOL || PRO == PRO_UPCAT);     // the input is read through MaxPool / upsample + concat
+    constexpr bool pro = (PRO == PRO_GN || PRO == PRO_GN_GELU), pro_gelu = (PRO == PRO_GN_GELU);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     SKINNY_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -75,6 +141,8 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
     float* Abuf = smem;                                   // [nch][QZ][K_LDK]
     float* smean = Abuf + (size_t)nch * QZ * K_LDK;       // [NS]
     float* srstd = smean + NS;                            // [NS]
+    float* smean1 = srstd + NS;                           // [NS] x 2: statistics of the skip tensor (PRO_UPCAT)
+    float* srstd1 = smean1 + NS;
 
     // ---- the loads nothing depends on go out first: this wave's first weight item and the first batch of slab pieces (a launch of
     //      this kernel is a chain of dependent memory round trips -- statistics, slab, weights -- so they are overlapped) ----
@@ -107,10 +175,27 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
         qs[j] = q; cs[j] = ch * 8 + c4;                                                              \
         v[j] = *reinterpret_cast<const k_f32x4*>(a.src + (size_t)m * a.src_ld + ch * K_CK + c4 * 4); \
     }
-    SKINNY_LOAD_A(0)
+    if (!fused) SKINNY_LOAD_A(0)
 
     // ---- statistics of the samples the slab touches ----
     int bh_first = 0;
+    if (fused) {
+        const int lo = max(m0 - halo, 0), hi = min(m0 + M_T + halo, M) - 1;
+        bh_first = lo / HW;
+        const int ns = hi / HW - bh_first + 1;
+        // one wave per (tensor, sample): the source's statistics, then the skip tensor's
+        for (int t = wave; t < 2 * ns; t += K_WAVES) {
+            const bool second = t >= ns;
+            const StatsRef& st = second ? a.skip_stats : a.pro_stats;
+            if ((second && PRO != PRO_UPCAT) || st.p == nullptr) continue;
+            float mean, rstd;
+            sample_mean_rstd_wave(st, bh_first + (second ? t - ns : t), lane, mean, rstd);
+            if (lane == 0) {
+                (second ? smean1 : smean)[second ? t - ns : t] = mean;
+                (second ? srstd1 : srstd)[second ? t - ns : t] = rstd;
+            }
+        }
+    }
     if (pro) {
         const int lo = max(m0 - halo, 0), hi = min(m0 + M_T + halo, M) - 1;
         bh_first = lo / HW;
@@ -125,11 +210,26 @@ __global__ __launch_bounds__(K_NTHR, 1) void conv_skinny_kernel(const GemmArgs a
         }
     }
     for (int t = tid; t < nch * K_LDK; t += K_NTHR) Abuf[((t / K_LDK) * QZ + QA) * K_LDK + t % K_LDK] = 0.f;
-    if (pro) __syncthreads();
+    if (pro || fused) __syncthreads();
     SKINNY_STAMP(1)
 
+    if (fused) {
+        // ---- the slab through the resampling op: one piece at a time per thread (4 gathered loads each; a small launch) ----
+#pragma unroll 2
+        for (int p = tid; p < npiece; p += K_NTHR) {
+            const int c4 = p & 7, rq = p >> 3;
+            const int q = rq % QA, ch = rq / QA;
+            const int m = m0 - halo + q;
+            k_f32x4 x = skinny_fused_piece<PRO>(a, min(max(m, 0), M - 1), ch, c4, bh_first, smean, srstd, smean1, srstd1);
+            if (m < 0 || m >= M) x = k_f32x4{0.f, 0.f, 0.f, 0.f};
+            const k_f32x2 p0_ = ksplit2(x.x, x.y), p1_ = ksplit2(x.z, x.w);
+            float* row = Abuf + ((size_t)ch * QZ + q) * K_LDK;
+            *reinterpret_cast<k_f32x2*>(row + c4 * 2) = k_f32x2{p0_.x, p1_.x};        // hi
+            *reinterpret_cast<k_f32x2*>(row + 16 + c4 * 2) = k_f32x2{p0_.y, p1_.y};   // lo
+        }
+    }
     // ---- stage the whole slab: 8 pieces in flight per thread (the first batch was issued above) ----
-    for (int p0 = 0; p0 < npiece; p0 += K_NTHR * 8) {
+    for (int p0 = 0; !fused && p0 < npiece; p0 += K_NTHR * 8) {
         if (p0) SKINNY_LOAD_A(p0)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -307,7 +407,7 @@ hipError_t launch_skinny_rc(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
     const int QA = M_T + 2 * halo;
     const int nch = a.K / K_CK;
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
-    size_t lds = ((size_t)nch * (QA + 1) * K_LDK + 2 * NS) * sizeof(float);
+    size_t lds = ((size_t)nch * (QA + 1) * K_LDK + 4 * NS) * sizeof(float);
     lds = std::max(lds, ((size_t)K_WAVES * M_T * N_T + (size_t)M_T * (N_T / 4) * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int grid = ((a.M + M_T - 1) / M_T) * (a.N / N_T);
@@ -321,6 +421,8 @@ hipError_t launch_skinny_rc(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
     }
     if (a.pro == PRO_NONE) SKINNY_GO(PRO_NONE)
     else if (a.pro == PRO_GN) SKINNY_GO(PRO_GN)
+    else if (a.pro == PRO_POOL) SKINNY_GO(PRO_POOL)
+    else if (a.pro == PRO_UPCAT) SKINNY_GO(PRO_UPCAT)
     else SKINNY_GO(PRO_GN_GELU)
 #undef SKINNY_GO
     return hipGetLastError();
@@ -385,7 +487,18 @@ hipError_t launch_conv_skinny(const GemmArgs& a, const GemmGeom& g, hipStream_t 
     if (!a.split || a.wgt_frag == nullptr || a.epi != EPI_STATS || a.epi_stats == nullptr || a.row_stats != nullptr || a.ksplit > 1)
         return hipErrorInvalidValue;
     if (a.M % a.HW != 0 || a.K % K_CK != 0 || a.N % g.n_tile != 0 || a.dst_ld % 4 != 0 || a.src_ld % 4 != 0) return hipErrorInvalidValue;
-    if (a.pro != PRO_NONE && (a.pro_stats.p == nullptr || a.pro_gamma == nullptr || a.pro_beta == nullptr)) return hipErrorInvalidValue;
+    const bool fused = a.pro == PRO_POOL || a.pro == PRO_UPCAT;
+    if (!fused && a.pro != PRO_NONE && (a.pro_stats.p == nullptr || a.pro_gamma == nullptr || a.pro_beta == nullptr)) return hipErrorInvalidValue;
+    if (fused) {        // shape contract of the fused sources (kernels.h): checked here so that a bad plan cannot fault the GPU
+        if (a.H < 1 || a.W < 1 || a.HW != a.H * a.W) return hipErrorInvalidValue;
+        if (a.pro_stats.p != nullptr && (a.pro_gamma == nullptr || a.pro_beta == nullptr)) return hipErrorInvalidValue;
+        if (a.pro == PRO_POOL && a.src_ld < a.K) return hipErrorInvalidValue;
+        if (a.pro == PRO_UPCAT) {
+            if ((a.H & 1) || (a.W & 1) || a.up_C <= 0 || a.up_C >= a.K || a.up_C % K_CK != 0 || a.src_ld < a.up_C || a.skip == nullptr ||
+                a.skip_ld < a.K - a.up_C || a.skip_ld % 4 != 0) return hipErrorInvalidValue;
+            if (a.skip_stats.p != nullptr && (a.skip_gamma == nullptr || a.skip_beta == nullptr)) return hipErrorInvalidValue;
+        }
+    }
     if (g.n_tile == 64) {
         if (g.m_tile == 64) return launch_skinny_rc<4, 4>(a, g, s);
         if (g.m_tile == 32) return launch_skinny_rc<2, 4>(a, g, s);

@@ -124,6 +124,26 @@ __device__ __forceinline__ void sample_mean_rstd_wave(const StatsRef& st, int b,
     rstd = (float)(1.0 / sqrt(var + 1e-5));
 }
 
+// The FiLM tail of a Down/UpSample block (models/Unet_FiLmLayer.py:165-177: x = GN(x); x = x + emb_t; x = scale x + bias) as
+// the affine y = A x + B of the raw conv output, for sample b: dst[0, C) = A = scale rstd gamma, dst[C, 2C) = B =
+// scale (beta - mean rstd gamma + emb_t) + bias.  One WAVE per sample (all 64 lanes call it); same arithmetic as
+// film_coef_kernel (elementwise.hip), which stays as the fallback.
+__device__ __forceinline__ void film_coef_row_wave(const FilmSpec& f, int b, int lane, float* dst) {
+    const int C = f.C;
+    const int t = (f.temb != nullptr) ? f.t_dev[f.t_count == 1 ? 0 : b] : 0;
+    float mean = 0.f, rstd = 1.f;
+    if (f.st.p != nullptr) sample_mean_rstd_wave(f.st, b, lane, mean, rstd);
+    for (int c = lane; c < C; c += 64) {
+        float sc = 1.f, be = 0.f;
+        if (f.st.p != nullptr) { sc = rstd * f.gamma[c]; be = f.beta[c] - mean * sc; }
+        if (f.temb != nullptr) be += f.temb[(size_t)t * C + c];
+        float fs = 1.f, fb = 0.f;
+        if (f.film != nullptr) { fs = f.film[(size_t)b * 2 * C + c]; fb = f.film[(size_t)b * 2 * C + C + c]; }
+        dst[c] = fs * sc;
+        dst[C + c] = fs * be + fb;
+    }
+}
+
 // Sum over the 16 lanes of a DPP row (quad swaps, half-mirror, mirror): every lane ends with the row total.  Four VALU
 // operations, no LDS traffic; the same additions as the xor butterfly 1, 2, 4, 8 (a + b == b + a), so bit-identical to it.
 __device__ __forceinline__ float row16_sum_dpp(float v) {

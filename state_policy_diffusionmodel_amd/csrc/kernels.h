@@ -57,6 +57,7 @@ enum : unsigned {
     SW_T3_BIG = 1u << 5, SW_NO_SMALL_TPI3 = 1u << 6, SW_WIDE_N64_2X2 = 1u << 7, SW_NO_SA_FUSED = 1u << 8,
     SW_NO_SA_TAIL = 1u << 9, SW_ATTN_VALU = 1u << 10, SW_SA_NO_WLDS = 1u << 11, SW_NO_FILM_FOLD = 1u << 12,
     SW_NO_GRAPH = 1u << 13, SW_NO_SPLITK = 1u << 14, SW_ARENA_TRACE = 1u << 15, SW_NO_WIDE_PIPE = 1u << 16, SW_NO_SKINNY = 1u << 17, SW_DEEP = 1u << 18,
+    SW_NO_FILM_LOCAL = 1u << 19, SW_NO_FUSED_SRC = 1u << 20,
 };
 struct SwitchName { const char* env; unsigned bit; };
 inline const SwitchName* switch_table(int* n) {
@@ -65,14 +66,17 @@ inline const SwitchName* switch_table(int* n) {
         {"SPDM_T512", SW_T512}, {"SPDM_T3_BIG", SW_T3_BIG}, {"SPDM_NO_SMALL_TPI3", SW_NO_SMALL_TPI3},
         {"SPDM_WIDE_N64_2X2", SW_WIDE_N64_2X2}, {"SPDM_NO_SA_FUSED", SW_NO_SA_FUSED}, {"SPDM_NO_SA_TAIL", SW_NO_SA_TAIL},
         {"SPDM_ATTN_VALU", SW_ATTN_VALU}, {"SPDM_SA_NO_WLDS", SW_SA_NO_WLDS}, {"SPDM_NO_FILM_FOLD", SW_NO_FILM_FOLD},
-        {"SPDM_NO_GRAPH", SW_NO_GRAPH}, {"SPDM_NO_SPLITK", SW_NO_SPLITK}, {"SPDM_ARENA_TRACE", SW_ARENA_TRACE}, {"SPDM_NO_WIDE_PIPE", SW_NO_WIDE_PIPE}, {"SPDM_NO_SKINNY", SW_NO_SKINNY}, {"SPDM_DEEP", SW_DEEP}};
+        {"SPDM_NO_GRAPH", SW_NO_GRAPH}, {"SPDM_NO_SPLITK", SW_NO_SPLITK}, {"SPDM_ARENA_TRACE", SW_ARENA_TRACE}, {"SPDM_NO_WIDE_PIPE", SW_NO_WIDE_PIPE}, {"SPDM_NO_SKINNY", SW_NO_SKINNY}, {"SPDM_DEEP", SW_DEEP},
+        {"SPDM_NO_FILM_LOCAL", SW_NO_FILM_LOCAL}, {"SPDM_NO_FUSED_SRC", SW_NO_FUSED_SRC}};
     *n = (int)(sizeof(t) / sizeof(t[0]));
     return t;
 }
 unsigned switches_from_env();          // spdm_api.hip
 int spdm_tune(int idx, int dflt);      // conv_gemm.hip: SPDM_TUNE<idx> (read once per process) or dflt -- tuning experiments only
 
-enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_GELU = 2 };
+// Load prologue of a convolution.  PRO_POOL / PRO_UPCAT: the FIRST convolution of a Down / UpSample block reads the block's input
+// through the resampling op itself (GemmArgs: "fused sources") instead of a materialised pooled / concatenated tensor.
+enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_GELU = 2, PRO_POOL = 3, PRO_UPCAT = 4 };
 enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RESID = 3, EPI_PLAIN = 4 };
 
 struct GemmArgs {
@@ -85,6 +89,14 @@ struct GemmArgs {
     int taps;                          // 1, 3 (vertical taps, W == 1) or 9
     int H, W, HW;                      // spatial dims of this level
     int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
+    // Fused sources (conv_skinny.hip, conv_wide.hip; gemm_takes_fused_source says which launches):
+    //   PRO_POOL : the conv input is MaxPool2d(2) (models/Unet_FiLmLayer.py:132,159) of src, src being the FINER level's tensor
+    //              [B][4 HW][K] -- a (2 H) x (2 W) map per sample -- with its pending GroupNorm in pro_stats / pro_gamma / pro_beta
+    //              (pro_stats.p == nullptr: none; the affine is applied per tap: max does not commute with a negative gain);
+    //   PRO_UPCAT: torch.cat([Upsample(x2, bilinear, align_corners=True)(x), x_res], dim=1) (:191,217-218): input channels
+    //              [0, up_C) are the upsample of src, the COARSER level's tensor [B][HW / 4][up_C] (pending GroupNorm in pro_*),
+    //              channels [up_C, K) are skip [B][HW][K - up_C] (pending GroupNorm in skip_*; skip_stats.p == nullptr: none).
+    int up_C;  const float* skip;  int skip_ld;  StatsRef skip_stats;  const float* skip_gamma;  const float* skip_beta;
     int epi;  double* epi_stats;   const float* bias;  const float* resid;  int resid_ld;
     double* row_stats;                 // optional: per-row {sum, sum^2} of the STORED values, [row][n_tiles][2] (LayerNorm of the consumer)
     // Split-K (small grids: few rows, long K).  ksplit > 1: the launch has ksplit x as many workgroups; workgroup (tile, ks)
@@ -125,6 +137,9 @@ hipError_t launch_conv_skinny(const GemmArgs& a, const GemmGeom& g, hipStream_t 
 hipError_t launch_splitk_combine(const float* partial, int ksplit, float* dst, int M, int N, int HW, double* stats,
                                  hipStream_t s);
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+// would launch_gemm run this statistics-epilogue convolution on a kernel that takes a fused source (pro = PRO_POOL / PRO_UPCAT)?
+// (a: the complete launch arguments, as launch_gemm would get them)
+bool gemm_takes_fused_source(const GemmArgs& a);
 double gemm_flops(const GemmArgs& a);
 // conv_wide.hip: the 4-wave / 128x64-per-wave configuration of the 3x3 implicit GEMM (256 x 128 tiles, two
 // workgroups per CU); launch_gemm routes to it when conv_wide_supported
@@ -174,6 +189,17 @@ hipError_t launch_upcat(const AffineSrc& up, const AffineSrc& skip, float* dst, 
 hipError_t launch_film_apply(const AffineSrc& src, const float* temb_table /*[T][C]*/, const int* t_dev,
                              int t_count, const float* film /*[B][2C] or null*/, float* dst, double* row_stats,
                              int B, int HW, hipStream_t s);
+// The same tail as a recipe: the attention kernels that read the block input themselves (sa_qkv / sa_tail / sa_fused64) evaluate
+// the coefficients of the samples their tile touches at kernel start (device_utils.h film_coef_row_wave: statistics slots, one
+// time-embedding row, the FiLM row) instead of reading them from a film_coef_kernel launch -- one launch per block less, which is
+// what a small-batch step is made of (64 launches of ~5-8 us at batch 1).
+struct FilmSpec {
+    StatsRef st; const float* gamma; const float* beta;   // GroupNorm(1,C) still pending on the raw tensor (st.p may be null)
+    const float* temb; const int* t_dev; int t_count;     // time-embedding table [T][C] and the device timestep(s); temb may be null
+    const float* film;                                    // [B][2C] = [scale | bias] of the FiLM encoder, or null
+    int C;
+    int on;                                               // 0: unused (the consumer takes `ab` from memory, or nothing)
+};
 // the same tail as per-(sample, channel) coefficients ab[b] = [A (C) | B (C)], y = A x + B, for consumers that apply it on load
 hipError_t launch_film_coef(const AffineSrc& src, const float* temb_table, const int* t_dev, int t_count, const float* film,
                             float* ab, int B, hipStream_t s);
@@ -224,15 +250,18 @@ bool sa_fused_supported(int L, int C);
 // ab (optional): the block input is ab-affine of x per sample (film_coef_kernel), applied on load
 hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
-                             const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s);
+                             const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s,
+                             const FilmSpec* fs = nullptr);
 
 // ---- row-wise tail of a C = 128 / 256 SelfAttention block (sa_tail.hip): out_proj + x -> LayerNorm -> ff1 -> GELU -> ff2 + av ----
 bool sa_tail_supported(int C, unsigned sw);
 hipError_t launch_sa_tail(int C, const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                           const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
-                          const float* ln_b, const float* ab, int L, hipStream_t s);
+                          const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs = nullptr);
+// may the two kernels evaluate the FiLM coefficients themselves for samples of L rows?  (their LDS row per touched sample)
+bool sa_tail_film_local(int C, int L);
 // qkv = LayerNorm(x) W_in^T + b_in of the same blocks (LayerNorm from the row itself)
 hipError_t launch_sa_qkv(int C, const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
-                         const float* ln_b, const float* ab, int L, hipStream_t s);
+                         const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs = nullptr);
 
 }  // namespace spdm

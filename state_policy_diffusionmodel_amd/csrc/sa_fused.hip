@@ -51,6 +51,7 @@ struct SaFusedArgs {
     const _Float16 *wqkv_h, *wqkv_l, *wo_h, *wo_l, *w1_h, *w1_l, *w2_h, *w2_l;   // [rows][64] permuted, x128, in fragment order
     const float *bqkv, *bo, *b1, *b2;
     const float* ab;       // optional [B][2][64]: the block input is y = A x + B per sample (FiLM tail folded into the load)
+    FilmSpec fs;           // fs.on: ... with the coefficients evaluated here (wave 0, film_coef_row_wave) instead of read from ab
 };
 
 __device__ __forceinline__ void sa_split(float x, _Float16& hi, _Float16& lo) {
@@ -252,10 +253,13 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
     // FiLM tail folded into the load (film_coef_kernel): the sample's [A | B] sits in LDS, every x load applies it.
     // (not in PAIR mode: its register budget is full, the plan keeps film_apply there)
     float* ab_s = reinterpret_cast<float*>(WLDS ? Wsl + (size_t)256 * SA_WROW : Wsh);     // the FiLM row (see the layout)
-    const bool fold = !PAIR && a.ab != nullptr;
+    const bool fold = !PAIR && (a.ab != nullptr || a.fs.on);
     if (fold) {
-        if (tid < 2 * SA_C / 4)
+        if (a.fs.on) {
+            if (tid < 64) film_coef_row_wave(a.fs, b, tid, ab_s);
+        } else if (tid < 2 * SA_C / 4) {
             *reinterpret_cast<s_f32x4*>(ab_s + 4 * tid) = *reinterpret_cast<const s_f32x4*>(a.ab + (size_t)b * 2 * SA_C + 4 * tid);
+        }
         __syncthreads();
     }
 
@@ -559,8 +563,10 @@ bool sa_fused_supported(int L, int C) { return C == SA_C && L >= 1 && L <= 512; 
 
 hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const float* ln1_g, const float* ln1_b,
                              const float* ln2_g, const float* ln2_b, const void* const w_hl[8], const float* bqkv,
-                             const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s) {
+                             const float* bo, const float* b1, const float* b2, const float* ab, unsigned sw, hipStream_t s,
+                             const FilmSpec* fs) {
     if (!sa_fused_supported(L, SA_C) || B <= 0) return hipErrorInvalidValue;
+    if (fs && (ab != nullptr || fs->C != SA_C)) return hipErrorInvalidValue;
     SaFusedArgs a{};
     a.x = x; a.out = out; a.L = L; a.nb = B;
     a.ln1_g = ln1_g; a.ln1_b = ln1_b; a.ln2_g = ln2_g; a.ln2_b = ln2_b;
@@ -569,8 +575,9 @@ hipError_t launch_sa_fused64(const float* x, float* out, int B, int L, const flo
     a.w1_h = (const _Float16*)w_hl[4]; a.w1_l = (const _Float16*)w_hl[5];
     a.w2_h = (const _Float16*)w_hl[6]; a.w2_l = (const _Float16*)w_hl[7];
     a.bqkv = bqkv; a.bo = bo; a.b1 = b1; a.b2 = b2; a.ab = ab;
+    if (fs) { a.fs = *fs; a.fs.on = 1; }
     const bool pair = L > 256;                                                    // two workgroups per trajectory
-    if (pair && ab != nullptr) return hipErrorInvalidValue;                       // (the plan keeps film_apply there)
+    if (pair && (ab != nullptr || fs != nullptr)) return hipErrorInvalidValue;    // (the plan keeps film_apply there)
     const int nwave = pair ? 8 : (L + 31) / 32;
     const int Lp = pair ? 512 : nwave * 32;
     const bool wlds = !pair && (nwave >= 4) && !(sw & SW_SA_NO_WLDS);      // long sequences: weights staged in LDS

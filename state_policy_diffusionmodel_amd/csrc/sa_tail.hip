@@ -52,6 +52,7 @@ struct SaTailArgs {
     const float *wf_o, *wf_1, *wf_2;            // fragment-order split weights (C x C each)
     const float *b_o, *b_1, *b_2, *ln_g, *ln_b;
     const float* ab; int L;                     // optional [M / L][2][C]: x is y = A x + B per sample of L rows (FiLM tail folded in)
+    FilmSpec fs;                                // fs.on: the coefficients are evaluated here, into LDS (ab is null then)
 };
 
 __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
@@ -86,6 +87,31 @@ __device__ __forceinline__ void tail_film_fold(tf32x4 (&v)[8], const float* __re
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float* ab_ = ab + (size_t)(min(m0 + S::RPP * i + srow0, M - 1) / L) * 2 * C + cq * 4;
+            v[i] = v[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + C);
+        }
+    }
+}
+
+// The same with the coefficients evaluated by this workgroup: abl[s] = [A | B] of sample b_first + s (LDS), filled by
+// tail_film_rows below; the fold reads them after the barrier that follows.
+template <int C>
+__device__ __forceinline__ void tail_film_rows(const FilmSpec& fs, int L, int m0, int M, int wave, int lane, float* abl) {
+    using S = TailShape<C>;
+    const int b_first = m0 / L, b_last = (min(m0 + S::TM, M) - 1) / L;
+    for (int sidx = wave; sidx <= b_last - b_first; sidx += 4) film_coef_row_wave(fs, b_first + sidx, lane, abl + (size_t)sidx * 2 * C);
+}
+template <int C>
+__device__ __forceinline__ void tail_film_fold_lds(tf32x4 (&v)[8], const float* abl, int L, int m0, int M, int cq, int srow0) {
+    using S = TailShape<C>;
+    const int b_first = m0 / L;
+    if (L % S::TM == 0) {
+        const tf32x4 A = *reinterpret_cast<const tf32x4*>(abl + cq * 4), B = *reinterpret_cast<const tf32x4*>(abl + C + cq * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * A + B;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* ab_ = abl + (size_t)(min(m0 + S::RPP * i + srow0, M - 1) / L - b_first) * 2 * C + cq * 4;
             v[i] = v[i] * *reinterpret_cast<const tf32x4*>(ab_) + *reinterpret_cast<const tf32x4*>(ab_ + C);
         }
     }
@@ -181,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     }
 
     TAIL_LOAD_B(0, a.wf_o, 0)
+    float* abl = smem + NCH * T_M * T_LDK;              // [samples of this tile][2 C]: FiLM coefficients evaluated here (fs.on)
     // the per-column parameters of every phase, fetched now: loaded where they are used, each cost its phase a memory round trip
     const tf32x4 bo = *reinterpret_cast<const tf32x4*>(a.b_o + c16 * 4);
     const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
@@ -204,7 +231,9 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
         av[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
     }
     if (a.ab != nullptr) tail_film_fold<C>(av, a.ab, a.L, m0, M, c16, srow0);
+    if (a.fs.on) tail_film_rows<C>(a.fs, a.L, m0, M, wave, lane, abl);          // (behind the o / x loads: one round trip, overlapped)
     __syncthreads();
+    if (a.fs.on) tail_film_fold_lds<C>(av, abl, a.L, m0, M, c16, srow0);      // (av is register work until the first pick-up)
     TAIL_STAMP(1)
 
     tf32x4 acc[RT][CT];
@@ -310,6 +339,7 @@ struct SaQkvArgs {
     const float* wf;                            // fragment-order split in_proj weight (3 C x C)
     const float *b_in, *ln_g, *ln_b;
     const float* ab; int L;                     // optional FiLM-tail coefficients, as in SaTailArgs
+    FilmSpec fs;
 };
 
 template <int C>
@@ -348,6 +378,12 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
             v[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
         }
         if (a.ab != nullptr) tail_film_fold<C>(v, a.ab, a.L, m0, M, c16, srow0);
+        if (a.fs.on) {          // coefficients evaluated here, in the (still dead) output-tile region behind the slab
+            float* abl = smem + NCH * T_M * T_LDK;
+            tail_film_rows<C>(a.fs, a.L, m0, M, wave, lane, abl);
+            __syncthreads();
+            tail_film_fold_lds<C>(v, abl, a.L, m0, M, c16, srow0);
+        }
         // (the NP row pieces go through the two cross-lane sums together, as in sa_tail_kernel)
         float part[NP];
 #pragma unroll
@@ -433,9 +469,19 @@ extern "C" int spdm_debug_tail_stamps(unsigned long long* out64) {
 
 bool sa_tail_supported(int C, unsigned sw) { return (C == 128 || C == 256) && !(sw & SW_NO_SA_TAIL); }
 
+// samples a tile of TM rows can touch when samples are L rows long
+static int film_rows_cap(int TM, int L) { return (TM + L - 2) / L + 1; }
+// In-kernel FiLM coefficients: one [A | B] row of 2 C floats in LDS per touched sample.  sa_qkv keeps them in its output-tile
+// region (32 KB, dead until the first product is done), sa_tail behind its slab (36.9 KB + rows must leave two workgroups per CU).
+bool sa_tail_film_local(int C, int L) {
+    if (!(C == 128 || C == 256) || L < 1) return false;
+    return (size_t)film_rows_cap(8192 / C, L) * 2 * C * sizeof(float) <= (size_t)24 * 1024;
+}
+
 hipError_t launch_sa_tail(int C, const float* o, const float* x, float* out, int rows, const float* wf_o, const float* wf_1,
                           const float* wf_2, const float* b_o, const float* b_1, const float* b_2, const float* ln_g,
-                          const float* ln_b, const float* ab, int L, hipStream_t s) {
+                          const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs) {
+    if (fs && (ab || L <= 0 || !sa_tail_film_local(C, L) || fs->C != C)) return hipErrorInvalidValue;
     if (rows <= 0 || (ab && L <= 0) || !o || !x || !out || !wf_o || !wf_1 || !wf_2 || !b_o || !b_1 || !b_2 || !ln_g || !ln_b)
         return hipErrorInvalidValue;
     if (C != 128 && C != 256) return hipErrorInvalidValue;
@@ -443,19 +489,23 @@ hipError_t launch_sa_tail(int C, const float* o, const float* x, float* out, int
     a.o = o; a.x = x; a.out = out; a.M = rows;
     a.wf_o = wf_o; a.wf_1 = wf_1; a.wf_2 = wf_2;
     a.b_o = b_o; a.b_1 = b_1; a.b_2 = b_2; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
+    if (fs) { a.fs = *fs; a.fs.on = 1; }
     const int TM = 8192 / C;
-    const size_t lds = (size_t)(C / 32) * TM * T_LDK * sizeof(float);          // 36.9 KB
+    const size_t lds = (size_t)(C / 32) * TM * T_LDK * sizeof(float)           // 36.9 KB
+                       + (fs ? (size_t)film_rows_cap(TM, L) * 2 * C * sizeof(float) : 0);
     if (C == 128) hipLaunchKernelGGL(sa_tail_kernel<128>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(sa_tail_kernel<256>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_sa_qkv(int C, const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
-                         const float* ln_b, const float* ab, int L, hipStream_t s) {
+                         const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs) {
+    if (fs && (ab || L <= 0 || !sa_tail_film_local(C, L) || fs->C != C)) return hipErrorInvalidValue;
     if (rows <= 0 || (ab && L <= 0) || !x || !qkv || !wf_in || !b_in || !ln_g || !ln_b) return hipErrorInvalidValue;
     if (C != 128 && C != 256) return hipErrorInvalidValue;
     SaQkvArgs a{};
     a.x = x; a.qkv = qkv; a.M = rows; a.wf = wf_in; a.b_in = b_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
+    if (fs) { a.fs = *fs; a.fs.on = 1; }
     const int TM = 8192 / C;
     const size_t lds = (size_t)((C / 32) * TM * T_LDK + TM * C) * sizeof(float);     // slab 36.9 KB + output tile 32 KB
     const void* kern = C == 128 ? reinterpret_cast<const void*>(sa_qkv_kernel<128>) : reinterpret_cast<const void*>(sa_qkv_kernel<256>);

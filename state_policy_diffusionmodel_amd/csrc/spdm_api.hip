@@ -186,6 +186,8 @@ struct spdm_handle {
         }
     } graph_key;
     long long graph_captures = 0;         // step graphs built so far (spdm_graph_captures)
+    int dry_fuse_mask = 0;                // dry runs only: bit k set = resampling op k (pool 0-2, upsample+concat 3-5) is read through
+                                          // by its consumer (Ctx::conv_fused) -- the workspace is sized for every combination
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_exec = nullptr;
     hipStream_t gstream = nullptr;        // blocking stream the loop runs on when the caller passes the NULL stream
@@ -288,6 +290,23 @@ extern "C" int spdm_schedule_tables(int32_t kind, int32_t T, int32_t n, float be
 }
 
 static int plan_forward(spdm_handle* h, int B, bool use_cond, hipStream_t s, Tensor* feat_out);
+// dry runs of the plan at max_batch for every fused / materialised combination of the six resampling ops (Ctx::conv_fused):
+// arena.peak ends as the largest of them (arena.dry must be set by the caller)
+static int dry_plan_all(spdm_handle* h) {
+    size_t peak = 0;
+    for (int mask = 0; mask < 64; ++mask) {
+        h->dry_fuse_mask = mask;
+        h->arena.peak = 0;
+        h->arena.reset();
+        Tensor feat;
+        const int rc = plan_forward(h, h->cfg.max_batch, true, nullptr, &feat);
+        if (rc != SPDM_OK) { h->dry_fuse_mask = 0; return rc; }
+        peak = std::max(peak, h->arena.peak);
+    }
+    h->dry_fuse_mask = 0;
+    h->arena.peak = peak;
+    return SPDM_OK;
+}
 
 // channel / tap geometry of every layer (UNet_Film.__init__, models/Unet_FiLmLayer.py:246-264); known
 // before any weight is loaded, so that create() can size the workspace with a dry run of the plan
@@ -356,8 +375,7 @@ extern "C" int spdm_create(const spdm_config* cfg, spdm_handle** out) {
         h->arena.dry = true;
         h->arena.keep = (cfg->flags & SPDM_FLAG_DEBUG_KEEP) != 0;
         h->arena.reset();
-        Tensor feat;
-        if ((rc = plan_forward(h, mb, true, nullptr, &feat))) break;
+        if ((rc = dry_plan_all(h))) break;
         h->arena.dry = false;
         h->arena.cap = align_up(h->arena.peak, 4096);
         hipError_t e = hipMalloc((void**)&h->arena.base, h->arena.cap);
@@ -584,10 +602,7 @@ static int replan_arena(spdm_handle* h) {
     (void)hipDeviceSynchronize();         // nothing may still be running in the slab about to be re-planned
     const bool keep = h->arena.keep;
     h->arena.dry = true;
-    h->arena.peak = 0;
-    h->arena.reset();
-    Tensor feat;
-    const int rc = plan_forward(h, h->cfg.max_batch, true, nullptr, &feat);
+    const int rc = dry_plan_all(h);
     h->arena.dry = false;
     h->arena.keep = keep;
     if (rc != SPDM_OK) return rc;
@@ -865,6 +880,64 @@ struct Ctx {
         free(mid);
         return out;
     }
+    // The FIRST convolution of a Down / UpSample block reading its input THROUGH the resampling op (GemmArgs "fused sources":
+    // PRO_POOL: MaxPool2d(2) of src0, the finer level's value; PRO_UPCAT: cat([upsample x2 of src0 (coarser level), skip])) --
+    // no pooled / concatenated tensor is written or read back, and one launch less.  Returns false, with nothing allocated or
+    // launched, when the kernel launch_gemm would pick for this shape does not take fused sources (the caller then materialises).
+    bool conv_fused(int mode, const Value& src0, const Value* skip, const ConvW& w, int level, const float* gamma,
+                    const float* beta, Value* out_v) {
+        if (err || !h->split || (h->sw & SW_NO_FUSED_SRC) || h->arena.keep || h->d_partial == nullptr) return false;
+        const int HW = HWl(level), M = B * HW;
+        if (dry) {
+            // sizing pass: the fused / materialised choice of a real run depends on its batch (launch geometry), so the dry runs walk
+            // every combination (spdm_handle::dry_fuse_mask) and the slab is sized for the worst
+            if (!((h->dry_fuse_mask >> fuse_slot) & 1)) return false;
+            const int split = (w.cin % 32 == 0) ? 1 : 0;
+            const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, split, h->sw, /*stats_epi=*/true);
+            Value out;
+            out.t = talloc(w.cout, level);
+            out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
+            out.gamma = gamma; out.beta = beta;
+            *out_v = out;
+            return true;
+        }
+        if (!h->weights_loaded || !w.ws || !w.wf) return false;
+        GemmArgs a{};
+        a.sw = h->sw;
+        a.split = 1;
+        a.src = src0.t.p; a.src_ld = src0.t.C; a.wgt = w.ws; a.wgt_frag = w.wf; a.dst_ld = w.cout;
+        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
+        a.H = Hl(level); a.W = Wl(level); a.HW = HW;
+        a.pro = mode;
+        if (src0.pending_gn()) { a.pro_stats = src0.st.ref; a.pro_gamma = src0.gamma; a.pro_beta = src0.beta; }
+        if (mode == PRO_UPCAT) {
+            if (!skip || src0.t.C + skip->t.C != w.cin) return false;
+            a.up_C = src0.t.C; a.skip = skip->t.p; a.skip_ld = skip->t.C;
+            if (skip->pending_gn()) { a.skip_stats = skip->st.ref; a.skip_gamma = skip->gamma; a.skip_beta = skip->beta; }
+        } else if (src0.t.C != w.cin) {
+            return false;
+        }
+        a.epi = EPI_STATS;
+        a.partial = h->d_partial;
+        if (!gemm_takes_fused_source(a)) return false;
+        const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, 1, h->sw, /*stats_epi=*/h->d_partial != nullptr);
+        Value out;
+        out.t = talloc(w.cout, level);
+        out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
+        out.gamma = gamma; out.beta = beta;
+        if (err) { *out_v = out; return true; }
+        a.dst = out.t.p; a.epi_stats = out.st.p;
+        const bool solo = h->prof && h->prof_open < 0;
+        if (solo) prof_begin();
+        if (h->prof && h->prof_open >= 0) {
+            h->prof_evts[h->prof_open].flops += gemm_flops(a);
+            h->prof_evts[h->prof_open].launches += 1;
+        }
+        check(launch_gemm(a, s), "conv3x3 implicit GEMM (fused source)");
+        if (solo) prof_end();
+        *out_v = out;
+        return true;
+    }
     // y[rows][N] = x[rows][K] @ W^T + b  (+GELU | +resid)
     // per-token LayerNorm statistics buffer: [rows][n_tiles][2] fp64 (StatsRef with HW = 1: "sample" = row)
     StatsBuf row_stats_alloc(int rows, int C, int n_tiles) {
@@ -900,14 +973,15 @@ struct Ctx {
         return h->split && sa_fused_supported(HWl(level), w.C) && !(h->sw & SW_NO_SA_FUSED) && (!h->weights_loaded || w.fw[0]);
     }
     // ab (optional): x is the RAW conv output and the block input is ab-affine of it (film_coef); consumed here.
-    Tensor attention(Tensor& x, StatsBuf& xs, const AttnW& w, int level, Tensor* ab = nullptr) {
+    // fs (optional, instead of ab): the kernels evaluate those coefficients themselves (FilmSpec, kernels.h)
+    Tensor attention(Tensor& x, StatsBuf& xs, const AttnW& w, int level, Tensor* ab = nullptr, const FilmSpec* fs = nullptr) {
         const int L = HWl(level), rows = B * L, C = w.C;
         const float* abp = (ab && ab->valid) ? ab->p : nullptr;
         if (sa_fused(w, level)) {            // whole block in one kernel (sa_fused.hip)
             Tensor out = talloc(C, level);
             if (!err && !dry)
                 check(launch_sa_fused64(x.p, out.p, B, L, w.ln_g, w.ln_b, w.ff_ln_g, w.ff_ln_b, w.fw, w.in_proj.b,
-                                        w.out_proj.b, w.ff1.b, w.ff2.b, abp, h->sw, s), "fused attention block");
+                                        w.out_proj.b, w.ff1.b, w.ff2.b, abp, h->sw, s, fs), "fused attention block");
             free(x);
             free(xs);
             if (ab) free(*ab);
@@ -916,7 +990,7 @@ struct Ctx {
         Tensor qkv = ralloc(rows, 3 * C);
         if (h->split && sa_tail_supported(C, h->sw) && (!h->weights_loaded || w.qkv_wf)) {     // LayerNorm + in_proj in one 64-row kernel (sa_tail.hip)
             if (!err && !dry)
-                check(launch_sa_qkv(C, x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s), "attention in_proj");
+                check(launch_sa_qkv(C, x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s, fs), "attention in_proj");
         } else {
             linear(x.p, C, rows, w.in_proj, qkv.p, EPI_BIAS, nullptr, &xs, w.ln_g, w.ln_b);
         }
@@ -929,7 +1003,7 @@ struct Ctx {
             Tensor out = talloc(C, level);
             if (!err && !dry)
                 check(launch_sa_tail(C, att.p, x.p, out.p, rows, w.tail_wf[0], w.tail_wf[1], w.tail_wf[2], w.out_proj.b, w.ff1.b,
-                                        w.ff2.b, w.ff_ln_g, w.ff_ln_b, abp, L, s), "attention tail");
+                                        w.ff2.b, w.ff_ln_g, w.ff_ln_b, abp, L, s, fs), "attention tail");
             free(att);
             free(x);
             if (ab) free(*ab);
@@ -957,6 +1031,19 @@ struct Ctx {
         if (sa_fused(w, level)) return HWl(level) <= 256;      // (the two-workgroup mode for longer sequences has no registers left)
         return sa_tail_supported(w.C, h->sw) && (!h->weights_loaded || (w.qkv_wf && w.tail_wf[0]));
     }
+    // ... and may those kernels evaluate the coefficients themselves (no film_coef launch)?
+    bool film_local(const AttnW& w, int level) const {
+        if (!film_foldable(w, level) || (h->sw & SW_NO_FILM_LOCAL)) return false;
+        return sa_fused(w, level) || sa_tail_film_local(w.C, HWl(level));
+    }
+    FilmSpec film_spec(const Value& v, const ResampleW& w, int blk, bool use_cond) const {
+        FilmSpec f{};
+        if (v.pending_gn()) { f.st = v.st.ref; f.gamma = v.gamma; f.beta = v.beta; }
+        f.temb = w.temb_table; f.t_dev = h->d_t; f.t_count = h_tcount;
+        f.film = (use_cond && h->cfg.cond_dim > 0) ? h->d_film[blk] : nullptr;
+        f.C = w.cout; f.on = 1;
+        return f;
+    }
     // the FiLM tail as coefficients (film_coef_kernel): returns the RAW conv tensor of v (its statistics are released),
     // *ab receives [B][2 C]
     Tensor film_coef(Value& v, const ResampleW& w, int blk, bool use_cond, Tensor* ab) {
@@ -980,6 +1067,7 @@ struct Ctx {
         return y;
     }
     int h_tcount = 1;
+    int fuse_slot = 0;     // which resampling op conv_fused is being asked about (dry runs: bit of dry_fuse_mask)
     int adv = -2;          // loop bookkeeping done by conv_in_kernel: -2 none, -1 advance, >= 0 set
 };
 
@@ -1011,17 +1099,32 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
     static const char* xn[3] = {"x2", "x3", "x4"};
     for (int i = 0; i < 3; ++i) {
         const int lin = i, lout = i + 1;
-        Value p;
-        p.t = c.talloc(cur.t.C, lout);
-        if (!c.err && !c.dry)
-            c.check(launch_pool(c.asrc(cur), p.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "maxpool");
         // `cur` stays alive: it is a skip connection
-        c.prof_begin();
-        Value a = c.double_conv(p, h->down[i].dc1, lout);
+        Value a, mid;
+        c.fuse_slot = i;
+        if (c.conv_fused(PRO_POOL, cur, nullptr, h->down[i].dc1.first, lout, h->down[i].dc1.gamma, h->down[i].dc1.beta, &mid)) {
+            c.prof_begin();      // MaxPool2d(2) read through by the block's first conv (small grids)
+            a = c.conv(mid, h->down[i].dc1.second, lout, /*gelu=*/true, h->down[i].dc1.gamma, h->down[i].dc1.beta);
+            c.free(mid);
+        } else {
+            Value p;
+            p.t = c.talloc(cur.t.C, lout);
+            if (!c.err && !c.dry)
+                c.check(launch_pool(c.asrc(cur), p.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "maxpool");
+            c.prof_begin();
+            a = c.double_conv(p, h->down[i].dc1, lout);
+        }
         Value b2 = c.double_conv(a, h->down[i].dc2, lout);
         c.prof_end();
         StatsBuf ys;
         Tensor y, ab;
+        if (c.film_local(h->sa[i], lout)) {           // the attention kernels finish the block tail themselves, from the raw tensor
+            const FilmSpec fs = c.film_spec(b2, h->down[i], i, use_cond);
+            y = b2.t;
+            b2.t.valid = false;
+            y = c.attention(y, ys, h->sa[i], lout, nullptr, &fs);
+            c.free(b2);                               // (its statistics: released after the last launch that reads them is enqueued)
+        } else {
         if (c.film_foldable(h->sa[i], lout)) {
             y = c.film_coef(b2, h->down[i], i, use_cond, &ab);
         } else {
@@ -1030,6 +1133,7 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
             c.tap(dn[i], y);
         }
         if (h->cfg.attention) y = c.attention(y, ys, h->sa[i], lout, &ab);
+        }
         c.tap(xn[i], y);
         Value nv;
         nv.t = y;
@@ -1054,18 +1158,35 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
     for (int i = 0; i < 3; ++i) {
         const int lin = 3 - i, lout = 2 - i;
         Value& skip = skips[2 - i];
-        Value cat;
-        cat.t = c.talloc(cur.t.C + skip.t.C, lout);
-        if (!c.err && !c.dry)
-            c.check(launch_upcat(c.asrc(cur), c.asrc(skip), cat.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "upsample+concat");
-        c.free(cur);
-        c.free(skip);
-        c.prof_begin();
-        Value a = c.double_conv(cat, h->up[i].dc1, lout);
+        Value a, mid;
+        c.fuse_slot = 3 + i;
+        if (c.conv_fused(PRO_UPCAT, cur, &skip, h->up[i].dc1.first, lout, h->up[i].dc1.gamma, h->up[i].dc1.beta, &mid)) {
+            c.free(cur);         // upsample + concat read through by the block's first conv: released once that launch is enqueued
+            c.free(skip);
+            c.prof_begin();
+            a = c.conv(mid, h->up[i].dc1.second, lout, /*gelu=*/true, h->up[i].dc1.gamma, h->up[i].dc1.beta);
+            c.free(mid);
+        } else {
+            Value cat;
+            cat.t = c.talloc(cur.t.C + skip.t.C, lout);
+            if (!c.err && !c.dry)
+                c.check(launch_upcat(c.asrc(cur), c.asrc(skip), cat.t.p, B, c.Hl(lin), c.Wl(lin), c.s), "upsample+concat");
+            c.free(cur);
+            c.free(skip);
+            c.prof_begin();
+            a = c.double_conv(cat, h->up[i].dc1, lout);
+        }
         Value b3 = c.double_conv(a, h->up[i].dc2, lout);
         c.prof_end();
         StatsBuf ys;
         Tensor y, ab;
+        if (c.film_local(h->sa[3 + i], lout)) {
+            const FilmSpec fs = c.film_spec(b3, h->up[i], 3 + i, use_cond);
+            y = b3.t;
+            b3.t.valid = false;
+            y = c.attention(y, ys, h->sa[3 + i], lout, nullptr, &fs);
+            c.free(b3);
+        } else {
         if (c.film_foldable(h->sa[3 + i], lout)) {
             y = c.film_coef(b3, h->up[i], 3 + i, use_cond, &ab);
         } else {
@@ -1074,6 +1195,7 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
             c.tap(un[i], y);
         }
         if (h->cfg.attention) y = c.attention(y, ys, h->sa[3 + i], lout, &ab);
+        }
         c.tap(an[i], y);
         Value nv;
         nv.t = y;

@@ -98,7 +98,8 @@ def test_unfused_fallbacks_match_fused_paths(monkeypatch):
     x, cond = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["cond"]).cuda()
     outs = []
     for env in ({}, {"SPDM_NO_SA_FUSED": "1"}, {"SPDM_NO_SA_FUSED": "1", "SPDM_ATTN_VALU": "1"}, {"SPDM_NO_W2": "1", "SPDM_NO_T512": "1"},
-                {"SPDM_NO_FILM_FOLD": "1"}, {"SPDM_NO_SA_TAIL": "1"}, {"SPDM_NO_WIDE": "1"}):
+                {"SPDM_NO_FILM_FOLD": "1"}, {"SPDM_NO_SA_TAIL": "1"}, {"SPDM_NO_WIDE": "1"}, {"SPDM_NO_FILM_LOCAL": "1"},
+                {"SPDM_NO_FUSED_SRC": "1"}, {"SPDM_NO_FUSED_SRC": "1", "SPDM_NO_FILM_LOCAL": "1", "SPDM_NO_SKINNY": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = make_engine(32, 3, 1350, 2, sd, True)
