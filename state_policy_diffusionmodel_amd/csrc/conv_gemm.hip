@@ -858,6 +858,17 @@ bool gemm_takes_fused_source(const GemmArgs& a) {
     return g.skinny != 0;
 }
 
+// Two-source input (GemmArgs::skip with pro = PRO_NONE / PRO_GN: channels [0, up_C) from src, the rest from skip): conv_wide.hip's
+// 128-wide configurations.  Same question as above, for the plan's "upsample only, never concatenate" path.
+bool gemm_takes_two_sources(const GemmArgs& a0) {
+    if (a0.skip == nullptr || !a0.split || a0.wgt_frag == nullptr || (a0.sw & SW_NO_FUSED_SRC) || a0.epi != EPI_STATS) return false;
+    GemmArgs a = a0;
+    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    if (g.skinny || g.m_tile == 512) return false;
+    a.ksplit = g.ksplit;
+    return conv_wide_supported(a, g);
+}
+
 // 2 x MACs the launch actually evaluates (the W = 2 zero-tap skipping runs 6 of the 9 taps)
 static bool uses_w2(const GemmArgs& a, const GemmGeom& g) {
     return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && !(a.sw & SW_NO_W2);
@@ -898,8 +909,10 @@ hipError_t launch_gemm(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.ksplit = 1;
     const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    const bool fused_src = a.pro == PRO_POOL || a.pro == PRO_UPCAT;
+    if (fused_src && !g.skinny) return hipErrorInvalidValue;                            // (the plan asks gemm_takes_fused_source first)
+    if (!fused_src && a.skip != nullptr && !gemm_takes_two_sources(a)) return hipErrorInvalidValue;   // (... gemm_takes_two_sources)
     if (g.skinny) return launch_conv_skinny(a, g, s);
-    if (a.pro == PRO_POOL || a.pro == PRO_UPCAT) return hipErrorInvalidValue;      // (the plan asks gemm_takes_fused_source first)
     if (g.ksplit > 1) {
         if ((size_t)g.ksplit * a.M * a.N * sizeof(float) > SPLITK_WORKSPACE_BYTES || a.dst_ld != a.N) return hipErrorInvalidValue;
         a.ksplit = g.ksplit;
@@ -913,7 +926,7 @@ static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipSt
     // shape contract of the kernel -- checked on the host so that a bad plan can never fault the GPU
     if (a.M <= 0 || a.K <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (a.K % CK != 0 || a.N % 64 != 0) return hipErrorInvalidValue;
-    if (a.src_ld % 4 != 0 || a.src_ld < a.K || a.dst_ld % 4 != 0) return hipErrorInvalidValue;
+    if (a.src_ld % 4 != 0 || a.src_ld < (a.skip != nullptr ? a.up_C : a.K) || a.dst_ld % 4 != 0) return hipErrorInvalidValue;     // (two-source input: src holds the first up_C channels)
     if (a.epi == EPI_BIAS_RESID && a.resid_ld % 4 != 0) return hipErrorInvalidValue;
     if (!(a.taps == 1 || a.taps == 3 || a.taps == 9)) return hipErrorInvalidValue;
     if (a.taps != 1 && (a.W < 1 || a.W > 8 || a.H < 1 || a.HW != a.H * a.W || a.M % a.HW != 0)) return hipErrorInvalidValue;

@@ -92,7 +92,11 @@ __device__ __forceinline__ f32x2 split2(float a, float b) {
     return f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 
-template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE>
+// TWO: two-source input (the first convolution of an UpSample block, models/Unet_FiLmLayer.py:217-219): the 32-channel chunks
+// [0, up_C / 32) come from a.src -- the upsampled tensor, finished -- and the rest from a.skip, the skip connection, which is
+// what the prologue PRO (its pending GroupNorm) applies to.  torch.cat is then never materialised: upcat_kernel shrinks to the
+// upsample alone (no copy of the skip half: at up3 that copy was 268 MB in + 268 MB out per step at B = 4096).
+template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE, bool TWO = false>
 // launch bound (256, 2): a 256-register budget.  The 8 x 2 variants with a prologue then carry 88-128 bytes of scratch per lane
 // (stats finalisation state parked across the main loop); with (256, 1) the compiler allocates 203-250 registers and no scratch,
 // but schedules the loop worse: measured 10.5 vs 9.6-9.9 ms per step (same box, alternating).  Keep 2.
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     static_assert(!W2 || NT == 2, "the width-2 variant exists for 128-wide tiles");
     static_assert(RT == 8 || (RT == 4 && NT == 2 && !W2), "64-row waves only in the tap-pair loop");
     static_assert(WN == 2 || (WN == 1 && RT == 4), "the 4 x 1 wave arrangement uses 64-row waves");
+    static_assert(!TWO || (!PIPE && PRO != PRO_GN_GELU), "two-source input: first conv of a block, plain hand-over");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -199,6 +204,9 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         }
     }
     const float* abase = a.src + c4 * 4;
+    const float* abase1 = TWO ? a.skip + c4 * 4 : nullptr;        // chunks >= nc0 (two-source input)
+    const int nc0 = TWO ? a.up_C / CK : 0;
+    bool ident = false;                                           // the chunk being staged comes from a.src: no prologue on it
 
     // ---- A operand of row tile rt: lane (l16, kg) reads 16 bytes (8 fp16 of k = 8 kg ..) of slab row
     //      halo + wm 128 + ROWOFF(rt) + rowlane.  W2: rows permuted by parity (even tiles w = 0, odd tiles w = 1).
@@ -252,13 +260,19 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #define WIDE_LOAD_A(chunk_)                                                                          \
     {                                                                                                \
         WIDE_OPAQUE_ROW                                                                              \
+        const bool first_ = !TWO || (chunk_) < nc0;                                                  \
+        const int cc_ = (TWO && !first_) ? (chunk_) - nc0 : (chunk_);      /* chunk inside its tensor */ \
+        const float* ab_ = (first_ ? abase : abase1) + cc_ * CK;                                     \
+        const int ld_ = first_ ? a.src_ld : a.skip_ld;                                               \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                      \
             const int mc_ = min(max(m0 - halo + p_ * RP + srow_o, 0), M - 1);                        \
-            areg[p_] = *reinterpret_cast<const f32x4*>(abase + (size_t)mc_ * a.src_ld + (chunk_) * CK); \
+            areg[p_] = *reinterpret_cast<const f32x4*>(ab_ + (size_t)mc_ * ld_);                     \
         }                                                                                            \
         if (pro) {                                                                                   \
-            g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + (chunk_) * CK + c4 * 4);             \
-            b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + (chunk_) * CK + c4 * 4);              \
+            ident = TWO && first_;                                                                   \
+            g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + cc_ * CK + c4 * 4);                  \
+            b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + cc_ * CK + c4 * 4);                   \
+            if (TWO && first_) { g4r = f32x4{1.f, 1.f, 1.f, 1.f}; b4r = f32x4{0.f, 0.f, 0.f, 0.f}; } \
         }                                                                                            \
     }
 #define WIDE_STAGE_A()                                                                               \
@@ -267,7 +281,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
             f32x4 v_ = areg[p_];                                                                     \
             if (pro) {                                                                               \
                 const int bi_ = (int)((abidx >> (BB * p_)) & ((1ull << BB) - 1));                                  \
-                const float rs_ = srstd[bi_], mu_ = smean[bi_];                                      \
+                float rs_ = srstd[bi_], mu_ = smean[bi_];                                            \
+                if (TWO && ident) { rs_ = 1.f; mu_ = 0.f; }       /* (v - 0) (1 x 1) + 0 == v, bit for bit */ \
                 v_.x = (v_.x - mu_) * (rs_ * g4r.x) + b4r.x;                                         \
                 v_.y = (v_.y - mu_) * (rs_ * g4r.y) + b4r.y;                                         \
                 v_.z = (v_.z - mu_) * (rs_ * g4r.z) + b4r.z;                                         \
@@ -762,7 +777,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef WIDE_ROWOFF
 }
 
-template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false>
+template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false, bool TWO = false>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = (4 / WN) * RT * 16, N_T = WN * 32 * NT, NTHR = 256;
     constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 9) ? 128 : (APASS <= 10) ? 64 : 32;
@@ -776,7 +791,7 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     size_t lds = (size_t)((DB ? 2 : 1) * (QA + 2) * LDK + 2 * NS) * sizeof(float);
     lds = std::max(lds, (size_t)((M_T / (W2 ? 2 : WIDE_NH)) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE>;
+    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE, TWO>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     if (a.ksplit > 1 && a.K % 64 != 0) return hipErrorInvalidValue;          // split-K walks even chunk ranges
@@ -795,7 +810,11 @@ bool conv_wide_supported(const GemmArgs& a, const GemmGeom& g) {
     const bool common = a.split && a.wgt_frag != nullptr && a.W >= 1 && a.W <= 8 && (a.HW & 3) == 0 && a.M % a.HW == 0 &&
                         a.epi == EPI_STATS && a.row_stats == nullptr && a.K % CK == 0 &&
                         (a.debug & ~(DBG_STAMP | DBG_NO_MFMA | DBG_NO_WLOAD | DBG_NO_ALOAD)) == 0 && !(a.sw & SW_NO_WIDE);
-    if (!common) return false;
+    if (!common || a.pro > PRO_GN_GELU) return false;
+    if (a.skip != nullptr) {        // two-source input (TWO): 128-wide tilings, first conv of a block, whole chunks per tensor
+        if (a.pro == PRO_GN_GELU || a.up_C <= 0 || a.up_C >= a.K || a.up_C % CK != 0 || g.n_tile != 128 || a.skip_ld % 4 != 0 ||
+            a.skip_ld < a.K - a.up_C || a.src_ld < a.up_C) return false;
+    }
     if (a.ksplit > 1 && a.K % 64 != 0) return false;      // split-K walks even chunk ranges
     if ((g.m_tile + 2 * (a.W + 1) - 1) / a.HW + 2 > 128) return false;       // 7-bit packed sample index per staging pass
     if (g.m_tile == 128)            // small tiles: the tap-pair loop only (128-wide, taps walked in pairs)
@@ -817,6 +836,18 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
     // 64-wide 64-row-per-wave variant with >= 8 chunks (up2.dc2a 249 -> 218 us); neutral on 128 x 128 tiles; a loss where a
     // workgroup has few chunks (inc.b 330 -> 363) or 128 rows per wave (register spills, see below).  So: only there.
     const bool pipe = a.taps == 9 && a.K >= 256 && !(a.sw & SW_NO_WIDE_PIPE);
+    if (a.skip != nullptr) {        // two-source input: the three 128-wide configurations
+        if (g.m_tile == 128) {
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, true>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, true>(a, g, s);
+        }
+        if (wide_w2(a)) {
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, true, 8, 2, false, true>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN, true, 8, 2, false, true>(a, g, s);
+        }
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, true>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, true>(a, g, s);
+    }
     if (g.m_tile == 128) {
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4>(a, g, s);

@@ -140,6 +140,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 // would launch_gemm run this statistics-epilogue convolution on a kernel that takes a fused source (pro = PRO_POOL / PRO_UPCAT)?
 // (a: the complete launch arguments, as launch_gemm would get them)
 bool gemm_takes_fused_source(const GemmArgs& a);
+// ... or a two-source input (pro = PRO_NONE / PRO_GN with `skip` set: channels [0, up_C) from src, [up_C, K) from skip, the
+// prologue applying to the skip part only)?  conv_wide.hip's 128-wide configurations.
+bool gemm_takes_two_sources(const GemmArgs& a);
 double gemm_flops(const GemmArgs& a);
 // conv_wide.hip: the 4-wave / 128x64-per-wave configuration of the 3x3 implicit GEMM (256 x 128 tiles, two
 // workgroups per CU); launch_gemm routes to it when conv_wide_supported

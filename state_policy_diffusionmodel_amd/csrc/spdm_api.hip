@@ -187,7 +187,8 @@ struct spdm_handle {
     } graph_key;
     long long graph_captures = 0;         // step graphs built so far (spdm_graph_captures)
     int dry_fuse_mask = 0;                // dry runs only: bit k set = resampling op k (pool 0-2, upsample+concat 3-5) is read through
-                                          // by its consumer (Ctx::conv_fused) -- the workspace is sized for every combination
+                                          // by its consumer (Ctx::conv_fused), bits 6-8 = up block k - 6 takes the two-source
+                                          // conv (Ctx::conv_two) -- the workspace is sized for every combination
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_exec = nullptr;
     hipStream_t gstream = nullptr;        // blocking stream the loop runs on when the caller passes the NULL stream
@@ -294,7 +295,8 @@ static int plan_forward(spdm_handle* h, int B, bool use_cond, hipStream_t s, Ten
 // arena.peak ends as the largest of them (arena.dry must be set by the caller)
 static int dry_plan_all(spdm_handle* h) {
     size_t peak = 0;
-    for (int mask = 0; mask < 64; ++mask) {
+    for (int mask = 0; mask < 512; ++mask) {      // bits 0-2 pool read through, 3-5 upsample + concat read through, 6-8 two-source conv
+        if (((mask >> 3) & (mask >> 6) & 7) != 0) continue;       // (a block is one or the other)
         h->dry_fuse_mask = mask;
         h->arena.peak = 0;
         h->arena.reset();
@@ -938,6 +940,70 @@ struct Ctx {
         *out_v = out;
         return true;
     }
+    // The first convolution of an UpSample block with a TWO-SOURCE input (conv_wide.hip TWO): channels [0, C_up) from `up2x`, the
+    // upsampled tensor (finished), the rest from the skip connection, whose pending GroupNorm is the load prologue.  torch.cat
+    // (models/Unet_FiLmLayer.py:218) is never materialised.  Returns false, nothing done, when the launch would not be a
+    // two-source configuration.
+    bool conv_two(const Tensor& up2x, const Value& skip, const ConvW& w, int level, const float* gamma, const float* beta, Value* out_v) {
+        if (err || !h->split || (h->sw & SW_NO_FUSED_SRC) || h->arena.keep) return false;
+        const int HW = HWl(level), M = B * HW;
+        if (up2x.C + skip.t.C != w.cin) return false;
+        if (dry) {                       // sizing pass (see conv_fused): bit 6 + block of dry_fuse_mask
+            if (!((h->dry_fuse_mask >> (3 + fuse_slot)) & 1)) return false;
+            const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, (w.cin % 32 == 0) ? 1 : 0, h->sw, /*stats_epi=*/true);
+            Value out;
+            out.t = talloc(w.cout, level);
+            out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
+            out.gamma = gamma; out.beta = beta;
+            *out_v = out;
+            return true;
+        }
+        if (!h->weights_loaded || !w.ws || !w.wf) return false;
+        GemmArgs a{};
+        a.sw = h->sw;
+        a.split = 1;
+        a.src = up2x.p; a.src_ld = up2x.C; a.wgt = w.ws; a.wgt_frag = w.wf; a.dst_ld = w.cout;
+        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
+        a.H = Hl(level); a.W = Wl(level); a.HW = HW;
+        a.up_C = up2x.C; a.skip = skip.t.p; a.skip_ld = skip.t.C;
+        a.pro = skip.pending_gn() ? PRO_GN : PRO_NONE;
+        if (skip.pending_gn()) { a.pro_stats = skip.st.ref; a.pro_gamma = skip.gamma; a.pro_beta = skip.beta; }
+        a.epi = EPI_STATS;
+        a.partial = h->d_partial;
+        if (!gemm_takes_two_sources(a)) return false;
+        const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, 1, h->sw, /*stats_epi=*/h->d_partial != nullptr);
+        Value out;
+        out.t = talloc(w.cout, level);
+        out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
+        out.gamma = gamma; out.beta = beta;
+        *out_v = out;
+        if (err) return true;
+        a.dst = out.t.p; a.epi_stats = out.st.p;
+        const bool solo = h->prof && h->prof_open < 0;
+        if (solo) prof_begin();
+        if (h->prof && h->prof_open >= 0) {
+            h->prof_evts[h->prof_open].flops += gemm_flops(a);
+            h->prof_evts[h->prof_open].launches += 1;
+        }
+        check(launch_gemm(a, s), "conv3x3 implicit GEMM (two-source input)");
+        if (solo) prof_end();
+        return true;
+    }
+    // would conv_two take this block?  (asked BEFORE the upsample is launched)
+    bool conv_two_ok(int C_up, const Value& skip, const ConvW& w, int level) const {
+        if (err || !h->split || (h->sw & SW_NO_FUSED_SRC) || h->arena.keep) return false;
+        if (dry) return C_up + skip.t.C == w.cin && ((h->dry_fuse_mask >> (3 + fuse_slot)) & 1);
+        if (!h->weights_loaded || !w.ws || !w.wf) return false;
+        const int HW = HWl(level);
+        GemmArgs a{};
+        a.sw = h->sw; a.split = 1;
+        a.src = skip.t.p; a.src_ld = C_up; a.wgt = w.ws; a.wgt_frag = w.wf; a.dst_ld = w.cout;     // (src: any non-null pointer; not dereferenced)
+        a.M = B * HW; a.K = w.cin; a.N = w.cout; a.taps = w.taps; a.H = Hl(level); a.W = Wl(level); a.HW = HW;
+        a.up_C = C_up; a.skip = skip.t.p; a.skip_ld = skip.t.C;
+        a.pro = skip.pending_gn() ? PRO_GN : PRO_NONE;
+        a.epi = EPI_STATS; a.partial = h->d_partial;
+        return C_up + skip.t.C == w.cin && gemm_takes_two_sources(a);
+    }
     // y[rows][N] = x[rows][K] @ W^T + b  (+GELU | +resid)
     // per-token LayerNorm statistics buffer: [rows][n_tiles][2] fp64 (StatsRef with HW = 1: "sample" = row)
     StatsBuf row_stats_alloc(int rows, int C, int n_tiles) {
@@ -1164,6 +1230,19 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
             c.free(cur);         // upsample + concat read through by the block's first conv: released once that launch is enqueued
             c.free(skip);
             c.prof_begin();
+            a = c.conv(mid, h->up[i].dc1.second, lout, /*gelu=*/true, h->up[i].dc1.gamma, h->up[i].dc1.beta);
+            c.free(mid);
+        } else if (c.conv_two_ok(cur.t.C, skip, h->up[i].dc1.first, lout)) {
+            // upsample only; the first conv reads [upsampled | skip] from the two tensors (no copy of the skip half)
+            Tensor u2 = c.talloc(cur.t.C, lout);
+            AffineSrc none{};
+            if (!c.err && !c.dry) c.check(launch_upcat(c.asrc(cur), none, u2.p, B, c.Hl(lin), c.Wl(lin), c.s), "upsample");
+            c.free(cur);
+            c.prof_begin();
+            if (!c.conv_two(u2, skip, h->up[i].dc1.first, lout, h->up[i].dc1.gamma, h->up[i].dc1.beta, &mid) && !c.err)
+                c.err = fail(SPDM_ERR_STATE, "plan: two-source convolution refused after it was offered");
+            c.free(u2);
+            c.free(skip);
             a = c.conv(mid, h->up[i].dc1.second, lout, /*gelu=*/true, h->up[i].dc1.gamma, h->up[i].dc1.beta);
             c.free(mid);
         } else {
