@@ -854,7 +854,7 @@ GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, 
 bool gemm_takes_fused_source(const GemmArgs& a) {
     if (!(a.pro == PRO_POOL || a.pro == PRO_UPCAT) || !a.split || a.wgt_frag == nullptr || (a.sw & SW_NO_FUSED_SRC) || a.epi != EPI_STATS) return false;
     if (a.pro == PRO_UPCAT && (a.up_C <= 0 || a.up_C >= a.K || a.up_C % CK != 0 || (a.H & 1) || (a.W & 1))) return false;
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    const GemmGeom g = gemm_geometry(a.geom_M > 0 ? a.geom_M : a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
     return g.skinny != 0;
 }
 
@@ -863,7 +863,7 @@ bool gemm_takes_fused_source(const GemmArgs& a) {
 bool gemm_takes_two_sources(const GemmArgs& a0) {
     if (a0.skip == nullptr || !a0.split || a0.wgt_frag == nullptr || (a0.sw & SW_NO_FUSED_SRC) || a0.epi != EPI_STATS) return false;
     GemmArgs a = a0;
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    const GemmGeom g = gemm_geometry(a.geom_M > 0 ? a.geom_M : a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
     if (g.skinny || g.m_tile == 512) return false;
     a.ksplit = g.ksplit;
     return conv_wide_supported(a, g);
@@ -874,7 +874,7 @@ static bool uses_w2(const GemmArgs& a, const GemmGeom& g) {
     return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && !(a.sw & SW_NO_W2);
 }
 double gemm_flops(const GemmArgs& a) {
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS);
+    const GemmGeom g = gemm_geometry(a.geom_M > 0 ? a.geom_M : a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS);
     const double taps = uses_w2(a, g) ? 6.0 : (double)a.taps;
     return 2.0 * (double)a.M * (double)a.N * (double)a.K * taps;
 }
@@ -908,7 +908,7 @@ static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipSt
 hipError_t launch_gemm(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.ksplit = 1;
-    const GemmGeom g = gemm_geometry(a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
+    const GemmGeom g = gemm_geometry(a.geom_M > 0 ? a.geom_M : a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
     const bool fused_src = a.pro == PRO_POOL || a.pro == PRO_UPCAT;
     if (fused_src && !g.skinny) return hipErrorInvalidValue;                            // (the plan asks gemm_takes_fused_source first)
     if (!fused_src && a.skip != nullptr && !gemm_takes_two_sources(a)) return hipErrorInvalidValue;   // (... gemm_takes_two_sources)

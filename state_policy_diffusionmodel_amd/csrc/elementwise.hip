@@ -77,12 +77,12 @@ int conv_in_parts(int Hp, int Wp, int B) { return (B < 256 && (Hp * Wp) % 64 == 
 
 hipError_t launch_conv_in(const float* x, const float* w, float* dst, double* stats, int B, int H0, int D,
                           int Hp, int Wp, int lh, int lw, int* step_dev, int* t_dev, const int* timesteps, int n_steps,
-                          int adv, hipStream_t s) {
+                          int adv, hipStream_t s, int B_geom) {
     const int HW = Hp * Wp;
     const size_t lds = (size_t)(HW + 8) * sizeof(float);
     if (lds > 64 * 1024 || B <= 0) return hipErrorInvalidValue;
     if (adv >= -1 && (!step_dev || !t_dev || !timesteps || n_steps < 1)) return hipErrorInvalidValue;
-    const int parts = conv_in_parts(Hp, Wp, B);
+    const int parts = conv_in_parts(Hp, Wp, B_geom > 0 ? B_geom : B);
     const StepAdvance sa{step_dev, t_dev, timesteps, n_steps, adv};
     hipLaunchKernelGGL(conv_in_kernel, dim3(B, parts), dim3(256), lds, s, x, w, dst, stats, stats_slots(HW, HW / parts, 1), H0, D,
                        Hp, Wp, lh, lw, sa);

@@ -57,7 +57,7 @@ enum : unsigned {
     SW_T3_BIG = 1u << 5, SW_NO_SMALL_TPI3 = 1u << 6, SW_WIDE_N64_2X2 = 1u << 7, SW_NO_SA_FUSED = 1u << 8,
     SW_NO_SA_TAIL = 1u << 9, SW_ATTN_VALU = 1u << 10, SW_SA_NO_WLDS = 1u << 11, SW_NO_FILM_FOLD = 1u << 12,
     SW_NO_GRAPH = 1u << 13, SW_NO_SPLITK = 1u << 14, SW_ARENA_TRACE = 1u << 15, SW_NO_WIDE_PIPE = 1u << 16, SW_NO_SKINNY = 1u << 17, SW_DEEP = 1u << 18,
-    SW_NO_FILM_LOCAL = 1u << 19, SW_NO_FUSED_SRC = 1u << 20,
+    SW_NO_FILM_LOCAL = 1u << 19, SW_NO_FUSED_SRC = 1u << 20, SW_FILM_LOCAL = 1u << 21, SW_PIN_GEOMETRY = 1u << 22,
 };
 struct SwitchName { const char* env; unsigned bit; };
 inline const SwitchName* switch_table(int* n) {
@@ -67,7 +67,8 @@ inline const SwitchName* switch_table(int* n) {
         {"SPDM_WIDE_N64_2X2", SW_WIDE_N64_2X2}, {"SPDM_NO_SA_FUSED", SW_NO_SA_FUSED}, {"SPDM_NO_SA_TAIL", SW_NO_SA_TAIL},
         {"SPDM_ATTN_VALU", SW_ATTN_VALU}, {"SPDM_SA_NO_WLDS", SW_SA_NO_WLDS}, {"SPDM_NO_FILM_FOLD", SW_NO_FILM_FOLD},
         {"SPDM_NO_GRAPH", SW_NO_GRAPH}, {"SPDM_NO_SPLITK", SW_NO_SPLITK}, {"SPDM_ARENA_TRACE", SW_ARENA_TRACE}, {"SPDM_NO_WIDE_PIPE", SW_NO_WIDE_PIPE}, {"SPDM_NO_SKINNY", SW_NO_SKINNY}, {"SPDM_DEEP", SW_DEEP},
-        {"SPDM_NO_FILM_LOCAL", SW_NO_FILM_LOCAL}, {"SPDM_NO_FUSED_SRC", SW_NO_FUSED_SRC}};
+        {"SPDM_NO_FILM_LOCAL", SW_NO_FILM_LOCAL}, {"SPDM_NO_FUSED_SRC", SW_NO_FUSED_SRC},
+        {"SPDM_FILM_LOCAL", SW_FILM_LOCAL}, {"SPDM_PIN_GEOMETRY", SW_PIN_GEOMETRY}};
     *n = (int)(sizeof(t) / sizeof(t[0]));
     return t;
 }
@@ -86,6 +87,8 @@ struct GemmArgs {
     const float* wgt_frag;             // optional: fragment-order copy of the split weights (frag_order_weights) -> conv_wide.hip
     float* dst;        int dst_ld;
     int M, K, N;
+    int geom_M;                        // > 0: choose tiles / split-K / kernel as for THIS many rows (SW_PIN_GEOMETRY: a shard of a larger batch
+                                       // then runs exactly the kernels the whole batch would, and reproduces it bit for bit)
     int taps;                          // 1, 3 (vertical taps, W == 1) or 9
     int H, W, HW;                      // spatial dims of this level
     int pro;  StatsRef pro_stats;  const float* pro_gamma;  const float* pro_beta;
@@ -175,7 +178,7 @@ inline std::vector<float> frag_order_weights(const std::vector<float>& split, in
 int conv_in_parts(int Hp, int Wp, int B);        // row parts per sample = statistics slots it writes (m_tile = HW / parts)
 hipError_t launch_conv_in(const float* x, const float* w /*[9][64]*/, float* dst, double* stats,
                           int B, int H0, int D, int Hp, int Wp, int lh, int lw, int* step_dev, int* t_dev,
-                          const int* timesteps_dev, int n_steps, int adv, hipStream_t s);
+                          const int* timesteps_dev, int n_steps, int adv, hipStream_t s, int B_geom = 0);     // B_geom > 0: row parts as for that batch
 
 struct AffineSrc {               // a tensor + the per-(sample,channel) affine that finishes it
     const float* x; int C;       // channels-last [B][HW][C]

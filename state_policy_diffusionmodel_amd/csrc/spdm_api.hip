@@ -748,6 +748,9 @@ struct Ctx {
     hipStream_t s;
     bool dry;
     int err = SPDM_OK;
+    // batch the launch geometry is chosen for: the call's, or -- SW_PIN_GEOMETRY -- always the handle's max_batch, so that a shard
+    // of a larger batch selects exactly the kernels (tiles, split-K, small-grid kernel, fused sources) the whole batch would
+    int Bg() const { return (h->sw & SW_PIN_GEOMETRY) ? h->cfg.max_batch : B; }
     int HWl(int l) const { return (h->Hp >> l) * (h->Wp >> l); }
     int Hl(int l) const { return h->Hp >> l; }
     int Wl(int l) const { return h->Wp >> l; }
@@ -819,7 +822,7 @@ struct Ctx {
         // by shape before the weights are known (the dry run at create); afterwards a tensor outside the split format's
         // range has no split copy and stays on the exact fp32 kernel (Loader::conv)
         const int split = (h->split && w.cin % 32 == 0 && (!h->weights_loaded || w.ws)) ? 1 : 0;
-        const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, split, h->sw, /*stats_epi=*/h->d_partial != nullptr);
+        const GemmGeom g = gemm_geometry(Bg() * HW, w.cout, w.cin, HW, Wl(level), w.taps, split, h->sw, /*stats_epi=*/h->d_partial != nullptr);
         out.t = talloc(w.cout, level);
         out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
         out.gamma = gamma; out.beta = beta;
@@ -830,7 +833,7 @@ struct Ctx {
         a.src = in.t.p; a.src_ld = in.t.C; a.wgt = a.split ? w.ws : w.w; a.dst = out.t.p; a.dst_ld = w.cout;
         a.wgt_frag = a.split ? w.wf : nullptr;
         if (a.wgt == nullptr) { if (!err) err = fail(SPDM_ERR_STATE, "plan: conv weights missing"); return out; }
-        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
+        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps; a.geom_M = Bg() * HW;
         a.H = Hl(level); a.W = Wl(level); a.HW = HW;
         a.pro = in.pending_gn() ? (gelu ? PRO_GN_GELU : PRO_GN) : PRO_NONE;
         if (in.pending_gn()) { a.pro_stats = in.st.ref; a.pro_gamma = in.gamma; a.pro_beta = in.beta; }
@@ -908,7 +911,7 @@ struct Ctx {
         a.sw = h->sw;
         a.split = 1;
         a.src = src0.t.p; a.src_ld = src0.t.C; a.wgt = w.ws; a.wgt_frag = w.wf; a.dst_ld = w.cout;
-        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
+        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps; a.geom_M = Bg() * HW;
         a.H = Hl(level); a.W = Wl(level); a.HW = HW;
         a.pro = mode;
         if (src0.pending_gn()) { a.pro_stats = src0.st.ref; a.pro_gamma = src0.gamma; a.pro_beta = src0.beta; }
@@ -922,7 +925,7 @@ struct Ctx {
         a.epi = EPI_STATS;
         a.partial = h->d_partial;
         if (!gemm_takes_fused_source(a)) return false;
-        const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, 1, h->sw, /*stats_epi=*/h->d_partial != nullptr);
+        const GemmGeom g = gemm_geometry(a.geom_M, w.cout, w.cin, HW, Wl(level), w.taps, 1, h->sw, /*stats_epi=*/h->d_partial != nullptr);
         Value out;
         out.t = talloc(w.cout, level);
         out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
@@ -963,7 +966,7 @@ struct Ctx {
         a.sw = h->sw;
         a.split = 1;
         a.src = up2x.p; a.src_ld = up2x.C; a.wgt = w.ws; a.wgt_frag = w.wf; a.dst_ld = w.cout;
-        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps;
+        a.M = M; a.K = w.cin; a.N = w.cout; a.taps = w.taps; a.geom_M = Bg() * HW;
         a.H = Hl(level); a.W = Wl(level); a.HW = HW;
         a.up_C = up2x.C; a.skip = skip.t.p; a.skip_ld = skip.t.C;
         a.pro = skip.pending_gn() ? PRO_GN : PRO_NONE;
@@ -971,7 +974,7 @@ struct Ctx {
         a.epi = EPI_STATS;
         a.partial = h->d_partial;
         if (!gemm_takes_two_sources(a)) return false;
-        const GemmGeom g = gemm_geometry(M, w.cout, w.cin, HW, Wl(level), w.taps, 1, h->sw, /*stats_epi=*/h->d_partial != nullptr);
+        const GemmGeom g = gemm_geometry(a.geom_M, w.cout, w.cin, HW, Wl(level), w.taps, 1, h->sw, /*stats_epi=*/h->d_partial != nullptr);
         Value out;
         out.t = talloc(w.cout, level);
         out.st = salloc(HW, w.cout, g.st_m_tile, g.st_n_tiles);
@@ -999,6 +1002,7 @@ struct Ctx {
         a.sw = h->sw; a.split = 1;
         a.src = skip.t.p; a.src_ld = C_up; a.wgt = w.ws; a.wgt_frag = w.wf; a.dst_ld = w.cout;     // (src: any non-null pointer; not dereferenced)
         a.M = B * HW; a.K = w.cin; a.N = w.cout; a.taps = w.taps; a.H = Hl(level); a.W = Wl(level); a.HW = HW;
+        a.geom_M = Bg() * HW;
         a.up_C = C_up; a.skip = skip.t.p; a.skip_ld = skip.t.C;
         a.pro = skip.pending_gn() ? PRO_GN : PRO_NONE;
         a.epi = EPI_STATS; a.partial = h->d_partial;
@@ -1027,6 +1031,7 @@ struct Ctx {
         a.split = (h->split && w.ws) ? 1 : 0;
         a.src = x; a.src_ld = ld; a.wgt = a.split ? w.ws : w.w; a.dst = y; a.dst_ld = w.out;
         a.M = rows; a.K = w.in; a.N = w.out; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
+        a.geom_M = (rows / B) * Bg();
         a.pro = PRO_NONE; a.epi = epi; a.bias = w.b; a.resid = resid; a.resid_ld = w.out;
         if (ln) { a.pro = PRO_GN; a.pro_stats = ln->ref; a.pro_gamma = ln_g; a.pro_beta = ln_b; }   // LayerNorm in the load prologue
         a.row_stats = row_stats_out;
@@ -1076,7 +1081,7 @@ struct Ctx {
             return out;
         }
         Tensor av = talloc(C, level);
-        const int nt_av = gemm_geometry(rows, C, C, 1, 1, 1, (h->split && w.out_proj.ws) ? 1 : 0, h->sw).n_tiles;   // n-tiles of the out_proj GEMM
+        const int nt_av = gemm_geometry((rows / B) * Bg(), C, C, 1, 1, 1, (h->split && w.out_proj.ws) ? 1 : 0, h->sw).n_tiles;   // n-tiles of the out_proj GEMM
         StatsBuf avs = row_stats_alloc(rows, C, nt_av);
         linear(att.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p, nullptr, nullptr, nullptr, avs.p);
         free(att);
@@ -1098,8 +1103,13 @@ struct Ctx {
         return sa_tail_supported(w.C, h->sw) && (!h->weights_loaded || (w.qkv_wf && w.tail_wf[0]));
     }
     // ... and may those kernels evaluate the coefficients themselves (no film_coef launch)?
+    // Only at the smallest batches (every launch a single workgroup): measured on the whole step (same box, alternating,
+    // graph replay), evaluating the coefficients inside the consumers saves 5 us per step at batch 1-4 (0.490 -> 0.485 ms) and
+    // COSTS 8 us at batch 64, 10-30 us at 512, ~50 us at 4096 -- every workgroup of sa_qkv / sa_tail repeats the statistics
+    // round trip and one barrier that the 5-us film_coef launch does once per sample.  SPDM_FILM_LOCAL=1 forces it on (tests).
     bool film_local(const AttnW& w, int level) const {
         if (!film_foldable(w, level) || (h->sw & SW_NO_FILM_LOCAL)) return false;
+        if (Bg() > 4 && !(h->sw & SW_FILM_LOCAL)) return false;
         return sa_fused(w, level) || sa_tail_film_local(w.C, HWl(level));
     }
     FilmSpec film_spec(const Value& v, const ResampleW& w, int blk, bool use_cond) const {
@@ -1144,11 +1154,11 @@ static int plan_unet(Ctx& c, const float* x, bool use_cond, Tensor* feat_out) {
     // ---- inc = DoubleConvolution(1, 64) on the zero-padded trajectory (:286-288) ----
     Value v0;
     v0.t = c.talloc(64, 0);
-    v0.st = c.salloc(c.HWl(0), 64, c.HWl(0) / conv_in_parts(h->Hp, h->Wp, B), 1);
+    v0.st = c.salloc(c.HWl(0), 64, c.HWl(0) / conv_in_parts(h->Hp, h->Wp, c.Bg()), 1);
     v0.gamma = h->inc.gamma; v0.beta = h->inc.beta;
     if (!c.err && !c.dry)
         c.check(launch_conv_in(x, h->w_inc_first, v0.t.p, v0.st.p, B, h->cfg.horizon, h->cfg.state_dim, h->Hp, h->Wp,
-                               h->lh, h->lw, h->d_step, h->d_t, h->d_timesteps, h->n_steps, c.adv, c.s), "conv_in");
+                               h->lh, h->lw, h->d_step, h->d_t, h->d_timesteps, h->n_steps, c.adv, c.s, c.Bg()), "conv_in");
     Value x1 = c.conv(v0, h->inc.second, 0, /*gelu=*/true, h->inc.gamma, h->inc.beta);   // x1 = GN(raw), pending
     c.free(v0);
     if (h->arena.keep) {
@@ -1328,6 +1338,7 @@ static int compute_film(spdm_handle* h, int B, const float* d_cond, hipStream_t 
         a.split = (h->split && blocks[i]->film.ws) ? 1 : 0;
         a.src = h->d_condm; a.src_ld = h->film_kp; a.wgt = a.split ? blocks[i]->film.ws : blocks[i]->film.w; a.dst = h->d_film[i]; a.dst_ld = 2 * blocks[i]->cout;
         a.M = B; a.K = h->film_kp; a.N = 2 * blocks[i]->cout; a.taps = 1; a.H = 1; a.W = 1; a.HW = 1;
+        a.geom_M = (h->sw & SW_PIN_GEOMETRY) ? h->cfg.max_batch : 0;
         a.pro = PRO_NONE; a.epi = EPI_BIAS; a.bias = blocks[i]->film.b;
         e = launch_gemm(a, s);
     }

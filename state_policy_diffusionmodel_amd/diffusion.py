@@ -143,16 +143,16 @@ class Diffusion_DDPM:
         return self
 
     # ------------------------------------------------------------------------------------------
-    def _engine_for(self, batch: int, H: int, D: int) -> SpdmEngine:
+    def _engine_for(self, batch: int, H: int, D: int, pin: bool = False) -> SpdmEngine:
         spec = _as_spec(self.noise_scheduler)
         T = max(int(spec.config.num_train_timesteps), int(self.noise_steps))
-        key = (H, D, T)
+        key = (H, D, T, batch if pin else 0)       # (a pinned engine is tied to ONE global batch)
         if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = SpdmEngine(H, D, self.cond_dim, max_batch=max(batch, self._max_batch),
+            self._engine = SpdmEngine(H, D, self.cond_dim, max_batch=batch if pin else max(batch, self._max_batch),
                                       device=self._device_index, attention=self.attention,
-                                      num_train_timesteps=T)
+                                      num_train_timesteps=T, pin_geometry=pin)
             self._engine.load_state_dict(self.noise_estimator._sd)
             self._engine_key = key
         return self._engine
@@ -166,7 +166,7 @@ class Diffusion_DDPM:
     def sample(self, batch: Dict[str, torch.Tensor], option: Optional[str] = None, *,
                x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
                batched: bool = False, seed: Optional[int] = None, sample_offset: int = 0, every: int = 1,
-               sharded: Optional[bool] = None, group=None):
+               sharded: Optional[bool] = None, group=None, shard_exact: bool = False):
         """``option``: None -> x_0 (B,1,H,D); 'sample_history' -> list of the N+1 iterates (the reference's form);
         'sample_history_stream' -> a generator of ``(i, x_i)`` host tensors handed out while the loop runs
         (``every``: stride in steps; SpdmEngine.sample_stream).
@@ -180,7 +180,10 @@ class Diffusion_DDPM:
         contiguous slice of the trajectories on its own GPU (no communication inside the loop) and one all-gather -- RCCL
         over xGMI on the "nccl" backend -- returns all B trajectories on every rank, rank-major, independent of the rank
         count (distributed.ShardedSampler).  None (default): shard iff a process group with more than one rank is
-        initialised.  ``x_T`` and ``seed`` left at None are drawn on rank 0 and broadcast."""
+        initialised.  ``x_T`` and ``seed`` left at None are drawn on rank 0 and broadcast.  A shard's trajectories agree
+        with the single-GPU run to fp32 rounding (<= 1e-5 over a loop: a small shard selects other kernels for the coarse
+        levels); ``shard_exact=True`` pins every rank's kernel selection to that of the GLOBAL batch instead -- bit-identical
+        to the single-GPU run, at the price of small-batch kernels not being used on small shards."""
         from .distributed import ShardedSampler, shard_bounds, world_and_rank
         world, rank = world_and_rank(group)
         if sharded is None:
@@ -211,7 +214,7 @@ class Diffusion_DDPM:
         spec = _as_spec(self.noise_scheduler)
         spec.set_timesteps(self.noise_steps)                                  # :257/:268
         s0, s1 = shard_bounds(B, rank, world) if sharded else (0, B)
-        eng = self._engine_for(s1 - s0, H, D)
+        eng = self._engine_for(B if (sharded and shard_exact) else s1 - s0, H, D, pin=bool(sharded and shard_exact))
         eng.set_scheduler(spec)
         ip = inpaint if self.inpaint_horizon > 0 else None
         if option == "sample_history_stream":

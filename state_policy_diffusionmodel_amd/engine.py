@@ -33,7 +33,7 @@ def _ptr(t: Optional[torch.Tensor]):
 class SpdmEngine:
     def __init__(self, horizon: int, state_dim: int, cond_dim: int, max_batch: int, device: int = 0,
                  attention: bool = True, time_dim: int = 256, num_train_timesteps: int = 1000,
-                 debug: bool = False, exact_fp32: bool = False):
+                 debug: bool = False, exact_fp32: bool = False, pin_geometry: bool = False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("SpdmEngine needs a visible MI355X (HIP device); there is no CPU fallback")
@@ -47,6 +47,11 @@ class SpdmEngine:
         h = ctypes.c_void_p()
         _lib.check(self.lib.spdm_create(ctypes.byref(cfg), ctypes.byref(h)), "spdm_create")
         self._h = h
+        if pin_geometry:
+            # kernel selection (tile sizes, split-K, the small-grid kernel, fused sources) normally follows the batch of the call;
+            # pinned, every call runs the kernels a batch of max_batch would -- so a rank that holds a shard of a larger batch
+            # (max_batch = the GLOBAL batch) reproduces the single-GPU trajectories bit for bit (multi-GPU)
+            _lib.check(self.lib.spdm_set_switch(self._h, b"SPDM_PIN_GEOMETRY", 1), "spdm_set_switch")
         self._keep = []           # tensors the C side reads asynchronously during a session
         self.n_steps = 0
         self.kind = None

@@ -99,7 +99,8 @@ def test_unfused_fallbacks_match_fused_paths(monkeypatch):
     outs = []
     for env in ({}, {"SPDM_NO_SA_FUSED": "1"}, {"SPDM_NO_SA_FUSED": "1", "SPDM_ATTN_VALU": "1"}, {"SPDM_NO_W2": "1", "SPDM_NO_T512": "1"},
                 {"SPDM_NO_FILM_FOLD": "1"}, {"SPDM_NO_SA_TAIL": "1"}, {"SPDM_NO_WIDE": "1"}, {"SPDM_NO_FILM_LOCAL": "1"},
-                {"SPDM_NO_FUSED_SRC": "1"}, {"SPDM_NO_FUSED_SRC": "1", "SPDM_NO_FILM_LOCAL": "1", "SPDM_NO_SKINNY": "1"}):
+                {"SPDM_NO_FUSED_SRC": "1"}, {"SPDM_NO_FUSED_SRC": "1", "SPDM_NO_FILM_LOCAL": "1", "SPDM_NO_SKINNY": "1"},
+                {"SPDM_FILM_LOCAL": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = make_engine(32, 3, 1350, 2, sd, True)
@@ -473,3 +474,55 @@ def test_every_batch_regime_agrees_with_single_trajectory_runs(H, D):
             assert float((got[B - 1] - last).abs().max()) <= 5e-6, (B, "last")
     finally:
         eng.close()
+
+
+def test_pinned_geometry_makes_a_shard_bit_identical_to_the_whole_batch():
+    """Kernel selection follows the batch (small-grid kernel, split-K, tile sizes, fused sources), so a shard of a batch agrees
+    with the whole-batch run only to fp32 rounding.  pin_geometry=True (SPDM_PIN_GEOMETRY) selects for max_batch whatever the
+    call's batch: engines sized for the GLOBAL batch then reproduce it bit for bit on any aligned shard -- the contract the
+    multi-GPU path offers callers that need it (Diffusion_DDPM.sample(..., shard_exact=True))."""
+    from state_policy_diffusionmodel_amd.engine import SpdmEngine
+    from state_policy_diffusionmodel_amd.schedulers import DDPMScheduler
+    B, H, D, cd, T = 192, 32, 3, 33, 4
+    sd = weights(cd, 21)
+    g = torch.Generator().manual_seed(4)
+    cond = torch.randn(B, 1, 3, 11, generator=g).cuda()
+    x_T = torch.rand(B, 1, H, D, generator=g).cuda()
+    res = {}
+    for pin in (False, True):
+        eng = SpdmEngine(H, D, cd, max_batch=B, num_train_timesteps=T, pin_geometry=pin)
+        eng.load_state_dict(sd)
+        s = DDPMScheduler(num_train_timesteps=T)
+        s.set_timesteps(T)
+        eng.set_scheduler(s)
+        try:
+            full = eng.sample(cond, x_T, seed=9).cpu()
+            parts = [eng.sample(cond[a:b], x_T[a:b], seed=9, sample_offset=a).cpu() for a, b in ((0, 64), (64, 128), (128, 192))]
+            res[pin] = (full, torch.cat(parts))
+        finally:
+            eng.close()
+    assert torch.equal(res[True][0], res[True][1])                              # pinned: bit for bit
+    assert float((res[False][0] - res[False][1]).abs().max()) <= 1e-5           # default: fp32 rounding
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5            # and both are the same trajectories
+
+
+def test_in_kernel_film_coefficients_match_the_coefficient_launch():
+    """The attention kernels may evaluate the FiLM-tail coefficients of their samples themselves (default at batch <= 4,
+    SPDM_FILM_LOCAL=1 forces it).  Forced on at batches and horizons where a row tile straddles several samples (L = 48, 12, 3
+    at horizon 24), it must agree with the film_coef_kernel path."""
+    cd = 33
+    sd = weights(cd, 21)
+    for H, D, B in ((24, 5, 37), (32, 3, 70), (8, 2, 9)):
+        g = torch.Generator().manual_seed(H + B)
+        x = torch.randn(B, 1, H, D, generator=g).cuda()
+        y = torch.randn(B, 1, 3, 11, generator=g).cuda()
+        t = (torch.arange(B) * 13) % 1000
+        eng = make_engine(H, D, cd, B, sd)
+        try:
+            ref = eng.unet_forward(x, t, y).cpu()
+            eng.set_switch("SPDM_FILM_LOCAL", True)
+            got = eng.unet_forward(x, t, y).cpu()
+            assert not eng.nonfinite()
+            assert float((got - ref).abs().max()) <= 2e-6, (H, D, B)
+        finally:
+            eng.close()
