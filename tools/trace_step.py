@@ -14,10 +14,10 @@ agg = {}
 for r in step:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += d
-    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("spdm::", "").replace("void ", "").split("(")[0][:46]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("spdm::", "").replace("void ", "").split("(")[0][:62]
     agg[n] = agg.get(n, 0.0) + d
     if "-v" in sys.argv:
-        print(f"{n:48s} grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):7d} vgpr={r['VGPR_Count']:>4s}+{r['Accum_VGPR_Count']:>3s} {d:9.1f} us")
+        print(f"{n:64s} grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):7d} vgpr={r['VGPR_Count']:>4s}+{r['Accum_VGPR_Count']:>3s} {d:9.1f} us")
 print(f"sum of kernels {tot/1e3:.2f} ms, wall {(int(step[-1]['End_Timestamp'])-int(step[0]['Start_Timestamp']))/1e6:.2f} ms")
 for n, d in sorted(agg.items(), key=lambda kv: -kv[1]):
-    print(f"  {n:48s} {d/1e3:8.3f} ms {100*d/tot:5.1f}%")
+    print(f"  {n:64s} {d/1e3:8.3f} ms {100*d/tot:5.1f}%")
