@@ -873,9 +873,17 @@ bool gemm_takes_two_sources(const GemmArgs& a0) {
 static bool uses_w2(const GemmArgs& a, const GemmGeom& g) {
     return a.split && g.m_tile == 256 && a.taps == 9 && a.W == 2 && a.HW % 2 == 0 && !(a.sw & SW_NO_W2);
 }
+// width-4 maps on conv_wide.hip's row-permuted variants: 20 of 24 tile steps per kernel row
+static bool uses_wp4(const GemmArgs& a0, const GemmGeom& g) {
+    if (!(a0.split && a0.taps == 9 && a0.W == 4 && g.n_tile == 128 && (g.m_tile == 128 || g.m_tile == 256) && a0.HW % 16 == 0 &&
+          a0.K % 64 == 0 && !(a0.sw & SW_NO_WP4)) || g.skinny) return false;
+    GemmArgs a = a0;
+    a.ksplit = g.ksplit;
+    return conv_wide_supported(a, g);
+}
 double gemm_flops(const GemmArgs& a) {
     const GemmGeom g = gemm_geometry(a.geom_M > 0 ? a.geom_M : a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS);
-    const double taps = uses_w2(a, g) ? 6.0 : (double)a.taps;
+    const double taps = uses_w2(a, g) ? 6.0 : uses_wp4(a, g) ? 7.5 : (double)a.taps;
     return 2.0 * (double)a.M * (double)a.N * (double)a.K * taps;
 }
 

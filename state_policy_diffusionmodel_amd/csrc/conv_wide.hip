@@ -26,6 +26,9 @@
 //     makes hipcc's waitcnt pass repeat the wait as vmcnt(0) at the next use, i.e. behind the weight loads;
 //   * width-2 maps (W2): rows are permuted by parity so that even row tiles hold w = 0 and odd ones w = 1 positions;
 //     a side column of the kernel then only concerns the tiles of one parity (32 instead of 48 tile steps per row);
+//   * width-4 maps (WP, round 3): the same idea one level up -- row tile rt of a wave holds the positions w = rt % 4 of a 64-row
+//     block (rows 4 l16 + w), so the left kernel column is skipped on the w = 0 tiles and the right one on the w = 3 tiles:
+//     20 instead of 24 tile steps per kernel row, only all-zero products dropped;
 //   * epilogue: 16-lane reductions by DPP adds, per-sample fp64 totals by a one-wave butterfly, tile through LDS in
 //     two 128-row halves so that every lane stores 16 bytes.
 #include <algorithm>
@@ -58,7 +61,23 @@ constexpr int CK = 32;
 #ifndef WIDE_LDS_PERM
 #define WIDE_LDS_PERM 1
 #endif
-template <bool W2, bool PIPE = false> struct WidePitch { static constexpr int value = (W2 || PIPE || !WIDE_LDS_PERM) ? 36 : 40; };
+template <bool W2, bool PIPE = false, bool WP = false> struct WidePitch { static constexpr int value = (W2 || PIPE || WP || !WIDE_LDS_PERM) ? 36 : 40; };
+// WP (width-4 maps): compile-time schedule of the row tiles a tap visits.  Tap t = 3 (dh + 1) + (dw + 1); the tiles of class
+// w = rt % 4 == 0 never see a valid dw = -1 tap, those of class 3 never a valid dw = +1 tap.
+constexpr bool wp_active(int t, int rt) { return !((t % 3 == 0 && (rt & 3) == 0) || (t % 3 == 2 && (rt & 3) == 3)); }
+constexpr int wp_first(int t) { return (t % 3 == 0) ? 1 : 0; }
+constexpr int wp_next(int t, int rt, int RT) {        // the next tile tap t visits after rt, or -1
+    for (int r = rt + 1; r < RT; ++r)
+        if (wp_active(t, r)) return r;
+    return -1;
+}
+constexpr int wp_order(int t, int rt, int RT) {       // position of (t, rt) in the chunk's sequence of tile steps
+    int n = 0;
+    for (int tt = 0; tt < t; ++tt)
+        for (int r = 0; r < RT; ++r) n += wp_active(tt, r) ? 1 : 0;
+    for (int r = 0; r < rt; ++r) n += wp_active(t, r) ? 1 : 0;
+    return n;
+}
 // (PIPE keeps two slabs: 2 x 276 rows only fit two workgroups per CU at the 144-byte pitch, and the conflict is harmless)
 #ifndef WIDE_STAGE_GROUP
 #define WIDE_STAGE_GROUP 1
@@ -96,7 +115,7 @@ __device__ __forceinline__ f32x2 split2(float a, float b) {
 // [0, up_C / 32) come from a.src -- the upsampled tensor, finished -- and the rest from a.skip, the skip connection, which is
 // what the prologue PRO (its pending GroupNorm) applies to.  torch.cat is then never materialised: upcat_kernel shrinks to the
 // upsample alone (no copy of the skip half: at up3 that copy was 268 MB in + 268 MB out per step at B = 4096).
-template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE, bool TWO = false>
+template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE, bool TWO = false, bool WP = false>
 // launch bound (256, 2): a 256-register budget.  The 8 x 2 variants with a prologue then carry 88-128 bytes of scratch per lane
 // (stats finalisation state parked across the main loop); with (256, 1) the compiler allocates 203-250 registers and no scratch,
 // but schedules the loop worse: measured 10.5 vs 9.6-9.9 ms per step (same box, alternating).  Keep 2.
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     constexpr int RP = NTHR / 8;
     constexpr int M_T = WM * RW, N_T = WN * NT * 32;
     constexpr int APASS = (M_T + 18 + RP - 1) / RP;
-    constexpr int FAR = W2 ? 4 : 3;                     // A-fragment ring (row tiles)
+    constexpr int FAR = (W2 || WP) ? 4 : 3;             // A-fragment ring (row tiles)
     constexpr int FBR = (NT == 2) ? 2 : 3;              // B-fragment ring (phases)
     constexpr int PH = 3 * NT;                          // phases per kernel row (generic layout)
     constexpr int BB = (APASS <= 9) ? 7 : (APASS <= 10) ? 6 : 5;   // bits per staging pass of the packed sample index
@@ -121,6 +140,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     static_assert(RT == 8 || (RT == 4 && NT == 2 && !W2), "64-row waves only in the tap-pair loop");
     static_assert(WN == 2 || (WN == 1 && RT == 4), "the 4 x 1 wave arrangement uses 64-row waves");
     static_assert(!TWO || (!PIPE && PRO != PRO_GN_GELU), "two-source input: first conv of a block, plain hand-over");
+    static_assert(!WP || (NT == 2 && WN == 2 && !W2 && !PIPE), "width-4 row permutation: 128-wide tiles, tap loop");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -146,8 +166,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     const int kc0 = 2 * (int)((long long)ks * (K / (2 * CK)) / ksp), kc1 = (ksp > 1) ? 2 * (int)((long long)(ks + 1) * (K / (2 * CK)) / ksp) : K / CK;
 
     static_assert(!PIPE || (NT == 2 && !W2), "the pipelined hand-over exists in the tap loop of 128-wide tiles");
-    constexpr int LDK = WidePitch<W2, PIPE>::value;                  // (shadows the namespace constant: every macro below uses it)
-    constexpr bool PERM = WIDE_LDS_PERM && !W2 && !PIPE;
+    constexpr int LDK = WidePitch<W2, PIPE, WP>::value;              // (shadows the namespace constant: every macro below uses it)
+    constexpr bool PERM = WIDE_LDS_PERM && !W2 && !PIPE && !WP;
     constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);       // (the other loops keep the single slab)
     float* Abuf = smem;                       // [QZ][LDK]: the slab the MFMA loop reads
     float* Awr = smem + (DB ? QZ * LDK : 0);  // the slab being staged (DB: the idle one of two)
@@ -211,8 +231,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     // ---- A operand of row tile rt: lane (l16, kg) reads 16 bytes (8 fp16 of k = 8 kg ..) of slab row
     //      halo + wm 128 + ROWOFF(rt) + rowlane.  W2: rows permuted by parity (even tiles w = 0, odd tiles w = 1).
     //      The 9 tap-validity bits of each of the 8 tiles are packed three tiles to a register. ----
-#define WIDE_ROWOFF(rt_) (W2 ? (((rt_) >> 1) * 32 + ((rt_) & 1)) : (rt_) * 16)
-    const int rowlane = W2 ? 2 * l16 : PERM ? (l16 < 4 ? l16 : l16 < 12 ? l16 + 4 : l16 - 8) : l16;
+#define WIDE_ROWOFF(rt_) (W2 ? (((rt_) >> 1) * 32 + ((rt_) & 1)) : WP ? (((rt_) >> 2) * 64 + ((rt_) & 3)) : (rt_) * 16)
+    const int rowlane = W2 ? 2 * l16 : WP ? 4 * l16 : PERM ? (l16 < 4 ? l16 : l16 < 12 ? l16 + 4 : l16 - 8) : l16;
     const int aoff0 = (wm * RW + rowlane + halo) * LDK + kg * 4;
     const int zoff = QA * LDK + kg * 4;
     unsigned am[(RT + 2) / 3] = {};
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     // slab-row shift (floats) of tap (kernel row kr_, column index dwi_ = dw + 1)
 #define WIDE_SHIFT(kr_, dwi_) ((((kr_) - 1) * W + ((dwi_) - 1)) * LDK)
 
-    if constexpr (!W2 && NT == 2) {
+    if constexpr (!W2 && NT == 2 && !(WP && RT == 8)) {
         // 128-wide tiles: one tap at a time with ALL four column tiles of the tap's weights in registers (two tap
         // slots = 64 registers), so every A fragment is read from LDS once per tap and feeds 12 MFMAs; the next
         // tap's weights are loaded a whole tap (96 MFMAs) ahead.  Loop body = two taps (compile-time slots); the
@@ -361,7 +381,75 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         const bool t3 = (TAPS == 3);
 #define TAP_SHIFT(tap_) (t3 ? ((tap_) - 1) * W * LDK : (((tap_) / 3 - 1) * W + ((tap_) - ((tap_) / 3) * 3 - 1)) * LDK)
 #define TAP_BIT(tap_) (t3 ? 3 * (tap_) + 1 : (tap_))
-        if constexpr (PIPE) {
+        if constexpr (WP) {
+            // Width-4 maps (3x3 kernels, host-checked a.W == 4): chunk-outer loop with the 9 taps unrolled, so the tile list of a
+            // tap is compile-time -- a runtime `if` around an MFMA group would cost the weight prefetch its overlap (see the
+            // header).  Tile steps per chunk: 3 x (RT + 2 (RT - RT / 4)): 60 for RT = 8, 30 for RT = 4, both even, so the
+            // two-slot A ring keeps its phase from chunk to chunk; tap 0 of the next chunk lands in weight slot 1 (9 is odd).
+#define WP_SHIFT(t_) ((((t_) / 3 - 1) * W + ((t_) % 3 - 1)) * LDK)
+            TAP_LOAD_B(0, kc0, 0)
+            WIDE_LOAD_A(kc0)
+            WIDE_STAGE_A()
+            __syncthreads();
+            WIDE_STAMP(2)
+            // (the 60 per-step fragment offsets are loop-invariant; hoisted out of the chunk loop they are 60 live registers and
+            //  the 128-row-per-wave variants spill ~270 bytes per lane.  An opaque copy of the lane's base offset, refreshed per
+            //  chunk, makes the compiler recompute each offset -- one select + one add -- where it is used.)
+            int aoff_w = aoff0;
+#define WP_LOAD_FA(slot_, tap_, shift_, rt_)                                                         \
+            {                                                                                        \
+                const unsigned mb_ = (am[(rt_) / 3] >> (9 * ((rt_) % 3) + (tap_))) & 1u;             \
+                const int o_ = mb_ ? aoff_w + WIDE_ROWOFF(rt_) * LDK + (shift_) : zoff;              \
+                fat[slot_][0] = *reinterpret_cast<const f16x8*>(Abuf + o_);                          \
+                fat[slot_][1] = *reinterpret_cast<const f16x8*>(Abuf + o_ + 16);                     \
+            }
+            WP_LOAD_FA(0, 0, WP_SHIFT(0), wp_first(0))
+            for (int chunk = kc0; chunk < kc1; ++chunk) {
+                const int cn1 = min(chunk + 1, kc1 - 1);        // (past the end: a harmless re-read)
+                asm volatile("" : "+v"(aoff_w));
+#pragma unroll
+                for (int i = 0; i < (RT + 2) / 3; ++i) asm volatile("" : "+v"(am[i]));      // (... and the 60 validity bits: SGPR pairs otherwise)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t < 8) { TAP_LOAD_B((t + 1) & 1, chunk, t + 1) } else { TAP_LOAD_B(1, cn1, 0) }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        {
+                            if (wp_active(t, rt)) {
+                                const int g = wp_order(t, rt, RT);
+                                const int nx = wp_next(t, rt, RT);
+                                if (nx >= 0) { WP_LOAD_FA((g + 1) & 1, t, WP_SHIFT(t), nx) }
+                                else if (t < 8) { WP_LOAD_FA((g + 1) & 1, t + 1, WP_SHIFT(t + 1), wp_first(t + 1)) }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (!dbg_no_mfma) {
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c)
+                                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[g & 1][0], fbt[t & 1][c][0], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c)
+                                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[g & 1][0], fbt[t & 1][c][1], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c)
+                                        acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[g & 1][1], fbt[t & 1][c][0], acc[rt][c], 0, 0, 0);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                }
+                if (chunk + 1 < kc1 && !dbg_no_aload) {
+                    WIDE_LOAD_A(chunk + 1)          // in flight across the barrier
+                    __syncthreads();                // every wave is done reading the slab of this chunk
+                    WIDE_STAGE_A()
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { fbt[0][c][0] = fbt[1][c][0]; fbt[0][c][1] = fbt[1][c][1]; }    // tap 0's weights sit in slot 1
+                WP_LOAD_FA(0, 0, WP_SHIFT(0), wp_first(0))
+            }
+#undef WP_SHIFT
+#undef WP_LOAD_FA
+        } else if constexpr (PIPE) {
             // Pipelined hand-over (3x3 kernels only: host).  Chunk-outer loop, the 9 taps unrolled, so tap, weight slot
             // and staging pass are compile-time.  While chunk c is multiplied, the slab of chunk c + 1 is built in the
             // idle buffer ONE 32-row pass per tap: pass t is transformed (GroupNorm affine, GELU, fp16 split) and written
@@ -522,6 +610,83 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef TAP_LOAD_FA
 #undef TAP_SHIFT
 #undef TAP_BIT
+    } else if constexpr (WP) {
+        // Width-4 maps, 128 rows per wave (the unrolled tap loop above spills at this size: its 64 weight registers; this loop
+        // keeps ONE column pair of a tap's weights, 32 registers, like the width-2 loop below, of which it is the generalisation).
+        // Row tile rt holds the positions w = rt % 4 of its 64-row block.  Kernel row = 6 phases: centre tap on all 8 row tiles
+        // (x 2 column pairs), dw = +1 on the six tiles with w < 3, dw = -1 on the six with w > 0: 40 tile steps instead of 48.
+        //   step q:  0..15 centre   16..27 (+1: tiles 0 1 2 4 5 6, pair 0 / 1)   28..39 (-1: tiles 1 2 3 5 6 7, pair 0 / 1)
+#define WP_PLUS(i_) ((i_) + (i_) / 3)
+#define WP_MINUS(i_) ((i_) + (i_) / 3 + 1)
+        WIDE_LOAD_B(0, kc0, 1, 0)
+        WIDE_LOAD_A(kc0)
+        WIDE_STAGE_A()
+        __syncthreads();
+        WIDE_STAMP(2)
+        WIDE_LOAD_FA(0, 1, WIDE_SHIFT(0, 1), 0)
+        WIDE_LOAD_FA(1, 1, WIDE_SHIFT(0, 1), 1)
+        int chunk = kc0, kr = 0;
+        for (int r = 0; r < nrows; ++r) {
+            int nkr = kr + 1, nchunk = chunk;
+            if (nkr == 3) { nkr = 0; nchunk = chunk + 1; }
+            const bool have_next = (r + 1 < nrows);
+            const bool next_A = have_next && (nkr == 0);
+            const int bkr = have_next ? nkr : kr, bchunk = have_next ? nchunk : chunk;
+            // ---- centre tap, all row tiles: steps q = 0..15 ----
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3 + 1, 1) } else { WIDE_LOAD_B(0, chunk, kr * 3 + 2, 0) }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int q = cp * 8 + rt;
+                    if (q + 2 < 16) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 1, WIDE_SHIFT(kr, 1), (q + 2) % 8) }
+                    else { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 2, WIDE_SHIFT(kr, 2), WP_PLUS(q + 2 - 16)) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WIDE_STEP(q % FAR, cp, rt, cp * 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- dw = +1 on the tiles with w < 3: steps 16..27 ----
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3 + 2, 1) } else { WIDE_LOAD_B(0, chunk, kr * 3, 0) }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int q = 16 + cp * 6 + i;
+                    if (q + 2 < 28) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 2, WIDE_SHIFT(kr, 2), WP_PLUS((q + 2 - 16) % 6)) }
+                    else { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), WP_MINUS(q + 2 - 28)) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WIDE_STEP(q % FAR, cp, WP_PLUS(i), cp * 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- dw = -1 on the tiles with w > 0: steps 28..39 ----
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3, 1) } else { WIDE_LOAD_B(0, bchunk, bkr * 3 + 1, 0) }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int q = 28 + cp * 6 + i;
+                    if (q + 2 < 40) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), WP_MINUS((q + 2 - 28) % 6)) }
+                    else if (have_next && !next_A) { WIDE_LOAD_FA((q + 2) % FAR, nkr * 3 + 1, WIDE_SHIFT(nkr, 1), q + 2 - 40) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    WIDE_STEP(q % FAR, cp, WP_MINUS(i), cp * 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (next_A) {
+                WIDE_LOAD_A(nchunk)
+                __syncthreads();
+                WIDE_STAGE_A()
+                __syncthreads();
+                WIDE_LOAD_FA(0, 1, WIDE_SHIFT(0, 1), 0)
+                WIDE_LOAD_FA(1, 1, WIDE_SHIFT(0, 1), 1)
+            }
+            kr = nkr;
+            chunk = nchunk;
+        }
+#undef WP_PLUS
+#undef WP_MINUS
     } else if constexpr (!W2) {
         // phase ph of a kernel row: tap column ph / NT, column-tile pair ph % NT
         WIDE_LOAD_B(0, kc0, 0, 0)
@@ -665,7 +830,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     // accumulator layout: lane (l16, kg), register j of tile (rt, ct) = row 16 rt + 4 rb4 + j, column 16 ct + l16, where
     // rb4 = kg, or {0, 2, 3, 1}[kg] under the row permutation of the A-fragment reads (WIDE_LDS_PERM)
     const int rb4 = PERM ? ((0x1320 >> (4 * kg)) & 0xF) : kg;
-    constexpr int NH = W2 ? 2 : WIDE_NH;                 // the tile leaves in NH parts (RW / NH rows of each wave per part)
+    constexpr int NH = W2 ? 2 : WP ? RT / 4 : WIDE_NH;   // the tile leaves in NH parts (RW / NH rows of each wave per part; WP: one 64-row block each)
     constexpr int HROWS = M_T / NH;
     const bool partial_out = ksp > 1;                    // split-K: raw partial tile to the workspace, statistics by the combine kernel
     float* const dstp = partial_out ? a.partial + (size_t)ks * M * N : a.dst;
@@ -676,7 +841,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     for (int rt = 0; rt < RT; ++rt) {
         // the lane's four registers are one 4-row unit (W2: rows 2 apart inside one 8-row block -> slot unit
         // 2 (block) + parity; a sample is still a contiguous run of HW / 4 slot units because HW % 8 == 0)
-        const int unit = wm * (RW / 4) + (W2 ? (rt >> 1) * 8 + 2 * kg + (rt & 1) : rt * 4 + rb4);
+        // WP: rows 4 apart inside one 16-row span -> slot unit 4 (span) + class; HW % 16 == 0 keeps a sample's units contiguous
+        const int unit = wm * (RW / 4) + (W2 ? (rt >> 1) * 8 + 2 * kg + (rt & 1) : WP ? (rt >> 2) * 16 + 4 * kg + (rt & 3) : rt * 4 + rb4);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -706,7 +872,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // row inside the wave's half (64 rows): W2 (rt>>1 - 2h) 32 + 2 (4 kg + j) + parity, else rq 16 + 4 kg + j
-                    const int rw = W2 ? ((rt >> 1) - 2 * h) * 32 + 2 * (4 * kg + j) + (rt & 1) : rq * 16 + 4 * rb4 + j;
+                    const int rw = W2 ? ((rt >> 1) - 2 * h) * 32 + 2 * (4 * kg + j) + (rt & 1) : WP ? 4 * (4 * kg + j) + (rt & 3) : rq * 16 + 4 * rb4 + j;
                     otile[(wm * (RW / NH) + rw) * N_T + col_l] = acc[rt][ct][j];
                 }
             }
@@ -777,7 +943,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef WIDE_ROWOFF
 }
 
-template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false, bool TWO = false>
+template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false, bool TWO = false, bool WP = false>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = (4 / WN) * RT * 16, N_T = WN * 32 * NT, NTHR = 256;
     constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 9) ? 128 : (APASS <= 10) ? 64 : 32;
@@ -786,12 +952,13 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);
-    constexpr int LDK = WidePitch<W2, PIPE>::value;
+    constexpr int LDK = WidePitch<W2, PIPE, WP>::value;
     if (PIPE && a.taps != 9) return hipErrorInvalidValue;
+    if (WP && (a.taps != 9 || a.W != 4 || a.HW % 16 != 0)) return hipErrorInvalidValue;
     size_t lds = (size_t)((DB ? 2 : 1) * (QA + 2) * LDK + 2 * NS) * sizeof(float);
-    lds = std::max(lds, (size_t)((M_T / (W2 ? 2 : WIDE_NH)) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
+    lds = std::max(lds, (size_t)((M_T / (W2 ? 2 : WP ? RT / 4 : WIDE_NH)) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE, TWO>;
+    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE, TWO, WP>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     if (a.ksplit > 1 && a.K % 64 != 0) return hipErrorInvalidValue;          // split-K walks even chunk ranges
@@ -836,6 +1003,26 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
     // 64-wide 64-row-per-wave variant with >= 8 chunks (up2.dc2a 249 -> 218 us); neutral on 128 x 128 tiles; a loss where a
     // workgroup has few chunks (inc.b 330 -> 363) or 128 rows per wave (register spills, see below).  So: only there.
     const bool pipe = a.taps == 9 && a.K >= 256 && !(a.sw & SW_NO_WIDE_PIPE);
+    // width-4 maps (level 1): the row-permuted variants skip the kernel's side columns on the w = 0 / w = 3 row tiles
+    if (a.W == 4 && a.taps == 9 && g.n_tile == 128 && a.HW % 16 == 0 && a.K % 64 == 0 && !(a.sw & SW_NO_WP4)) {
+        const bool two = a.skip != nullptr;
+        if (g.m_tile == 128) {
+            if (two) {
+                if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, true, true>(a, g, s);
+                return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, true, true>(a, g, s);
+            }
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, false, true>(a, g, s);
+            if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, false, true>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 2, false, false, true>(a, g, s);
+        }
+        if (two) {
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, true, true>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, true, true>(a, g, s);
+        }
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, false, true>(a, g, s);
+        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, false, true>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN_GELU, false, 8, 2, false, false, true>(a, g, s);
+    }
     if (a.skip != nullptr) {        // two-source input: the three 128-wide configurations
         if (g.m_tile == 128) {
             if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, true>(a, g, s);
