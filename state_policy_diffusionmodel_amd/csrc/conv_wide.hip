@@ -115,7 +115,10 @@ __device__ __forceinline__ f32x2 split2(float a, float b) {
 // [0, up_C / 32) come from a.src -- the upsampled tensor, finished -- and the rest from a.skip, the skip connection, which is
 // what the prologue PRO (its pending GroupNorm) applies to.  torch.cat is then never materialised: upcat_kernel shrinks to the
 // upsample alone (no copy of the skip half: at up3 that copy was 268 MB in + 268 MB out per step at B = 4096).
-template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE, bool TWO = false, bool WP = false>
+// G2 (experiment, opt-in SPDM_G2=1; see launch_conv_wide for the measurement): two 32-channel chunks per slab hand-over on the
+// 64-row-per-wave variants of the tap loop -- the loads of both chunks in flight together, one round trip and one barrier pair
+// per 64 channels.  Neutral to slower: the round trip is not what the hand-over costs.
+template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE, bool TWO = false, bool WP = false, bool G2 = false>
 // launch bound (256, 2): a 256-register budget.  The 8 x 2 variants with a prologue then carry 88-128 bytes of scratch per lane
 // (stats finalisation state parked across the main loop); with (256, 1) the compiler allocates 203-250 registers and no scratch,
 // but schedules the loop worse: measured 10.5 vs 9.6-9.9 ms per step (same box, alternating).  Keep 2.
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     static_assert(WN == 2 || (WN == 1 && RT == 4), "the 4 x 1 wave arrangement uses 64-row waves");
     static_assert(!TWO || (!PIPE && PRO != PRO_GN_GELU), "two-source input: first conv of a block, plain hand-over");
     static_assert(!WP || (NT == 2 && WN == 2 && !W2 && !PIPE), "width-4 row permutation: 128-wide tiles, tap loop");
+    static_assert(!G2 || (NT == 2 && RT == 4 && !W2 && !PIPE && !WP && !WIDE_DB), "two chunks per hand-over: the plain tap loop, 64 rows per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -166,12 +170,12 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     const int kc0 = 2 * (int)((long long)ks * (K / (2 * CK)) / ksp), kc1 = (ksp > 1) ? 2 * (int)((long long)(ks + 1) * (K / (2 * CK)) / ksp) : K / CK;
 
     static_assert(!PIPE || (NT == 2 && !W2), "the pipelined hand-over exists in the tap loop of 128-wide tiles");
-    constexpr int LDK = WidePitch<W2, PIPE, WP>::value;              // (shadows the namespace constant: every macro below uses it)
-    constexpr bool PERM = WIDE_LDS_PERM && !W2 && !PIPE && !WP;
+    constexpr int LDK = WidePitch<W2, PIPE, WP || G2>::value;        // (shadows the namespace constant: every macro below uses it)
+    constexpr bool PERM = WIDE_LDS_PERM && !W2 && !PIPE && !WP && !G2;
     constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);       // (the other loops keep the single slab)
     float* Abuf = smem;                       // [QZ][LDK]: the slab the MFMA loop reads
     float* Awr = smem + (DB ? QZ * LDK : 0);  // the slab being staged (DB: the idle one of two)
-    float* smean = smem + (DB ? 2 : 1) * QZ * LDK;     // [NS]
+    float* smean = smem + ((DB || G2) ? 2 : 1) * QZ * LDK;     // [NS]  (G2: the slab holds two chunks)
     float* srstd = smean + NS;                // [NS]
 
     // diagnostic builds: per-workgroup timeline {memrealtime, memtime x5, HW_ID, XCC_ID} (tools/bench_gemm.py --stamp)
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #endif
     WIDE_STAMP(1)
     if (tid < LDK) { Abuf[QA * LDK + tid] = 0.f; Awr[QA * LDK + tid] = 0.f; }
+    if (G2 && tid < LDK) Abuf[(QZ + QA) * LDK + tid] = 0.f;         // the all-zero row of the second chunk's sub-slab
 
     constexpr bool pro = (PRO != PRO_NONE);
     constexpr bool pro_gelu = (PRO == PRO_GN_GELU);
@@ -277,7 +282,9 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #else
 #define WIDE_OPAQUE_ROW if constexpr (PRO != PRO_NONE && RT == 8) asm volatile("" : "+v"(srow_o));
 #endif
-#define WIDE_LOAD_A(chunk_)                                                                          \
+#define WIDE_LOAD_A(chunk_) WIDE_LOAD_A_(chunk_, areg, g4r, b4r, ident)
+#define WIDE_STAGE_A() WIDE_STAGE_A_(areg, g4r, b4r, ident, Awr)
+#define WIDE_LOAD_A_(chunk_, areg_, g4r_, b4r_, ident_)                                              \
     {                                                                                                \
         WIDE_OPAQUE_ROW                                                                              \
         const bool first_ = !TWO || (chunk_) < nc0;                                                  \
@@ -286,27 +293,27 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         const int ld_ = first_ ? a.src_ld : a.skip_ld;                                               \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                      \
             const int mc_ = min(max(m0 - halo + p_ * RP + srow_o, 0), M - 1);                        \
-            areg[p_] = *reinterpret_cast<const f32x4*>(ab_ + (size_t)mc_ * ld_);                     \
+            areg_[p_] = *reinterpret_cast<const f32x4*>(ab_ + (size_t)mc_ * ld_);                     \
         }                                                                                            \
         if (pro) {                                                                                   \
-            ident = TWO && first_;                                                                   \
-            g4r = *reinterpret_cast<const f32x4*>(a.pro_gamma + cc_ * CK + c4 * 4);                  \
-            b4r = *reinterpret_cast<const f32x4*>(a.pro_beta + cc_ * CK + c4 * 4);                   \
-            if (TWO && first_) { g4r = f32x4{1.f, 1.f, 1.f, 1.f}; b4r = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+            ident_ = TWO && first_;                                                                   \
+            g4r_ = *reinterpret_cast<const f32x4*>(a.pro_gamma + cc_ * CK + c4 * 4);                  \
+            b4r_ = *reinterpret_cast<const f32x4*>(a.pro_beta + cc_ * CK + c4 * 4);                   \
+            if (TWO && first_) { g4r_ = f32x4{1.f, 1.f, 1.f, 1.f}; b4r_ = f32x4{0.f, 0.f, 0.f, 0.f}; } \
         }                                                                                            \
     }
-#define WIDE_STAGE_A()                                                                               \
+#define WIDE_STAGE_A_(areg_, g4r_, b4r_, ident_, dst_)                                                                             \
     {                                                                                                \
         _Pragma("unroll") for (int p_ = 0; p_ < APASS; ++p_) {                                      \
-            f32x4 v_ = areg[p_];                                                                     \
+            f32x4 v_ = areg_[p_];                                                                     \
             if (pro) {                                                                               \
                 const int bi_ = (int)((abidx >> (BB * p_)) & ((1ull << BB) - 1));                                  \
                 float rs_ = srstd[bi_], mu_ = smean[bi_];                                            \
-                if (TWO && ident) { rs_ = 1.f; mu_ = 0.f; }       /* (v - 0) (1 x 1) + 0 == v, bit for bit */ \
-                v_.x = (v_.x - mu_) * (rs_ * g4r.x) + b4r.x;                                         \
-                v_.y = (v_.y - mu_) * (rs_ * g4r.y) + b4r.y;                                         \
-                v_.z = (v_.z - mu_) * (rs_ * g4r.z) + b4r.z;                                         \
-                v_.w = (v_.w - mu_) * (rs_ * g4r.w) + b4r.w;                                         \
+                if (TWO && ident_) { rs_ = 1.f; mu_ = 0.f; }       /* (v - 0) (1 x 1) + 0 == v, bit for bit */ \
+                v_.x = (v_.x - mu_) * (rs_ * g4r_.x) + b4r_.x;                                         \
+                v_.y = (v_.y - mu_) * (rs_ * g4r_.y) + b4r_.y;                                         \
+                v_.z = (v_.z - mu_) * (rs_ * g4r_.z) + b4r_.z;                                         \
+                v_.w = (v_.w - mu_) * (rs_ * g4r_.w) + b4r_.w;                                         \
                 if (pro_gelu) {                                                                      \
                     v_.x = gelu_erf(v_.x); v_.y = gelu_erf(v_.y);                                    \
                     v_.z = gelu_erf(v_.z); v_.w = gelu_erf(v_.w);                                    \
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
             if (!((avalid >> p_) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                              \
             const f32x2 p0_ = split2(v_.x, v_.y), p1_ = split2(v_.z, v_.w);                          \
             {   /* rows past the slab go to a dump row: no branch (see the header) */                 \
-                float* row_ = Awr + min(p_ * RP + srow_o, QA + 1) * LDK;                             \
+                float* row_ = (dst_) + min(p_ * RP + srow_o, QA + 1) * LDK;                             \
                 *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{p0_.x, p1_.x};       /* hi */       \
                 *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{p0_.y, p1_.y};  /* lo */       \
             }                                                                                        \
@@ -552,6 +559,77 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef PIPE_GB
 #undef PIPE_STAGE
 #undef PIPE_SHIFT
+        } else if constexpr (G2) {
+        // Two chunks per hand-over: the slab is [2][QZ][LDK]; chunk c of the workgroup's range lives in sub-slab (c - kc0) & 1, the
+        // hand-over happens when the tap sequence enters an EVEN chunk and stages that chunk and the next one from two register
+        // sets whose loads were issued together (past the end of the range: a harmless duplicate of the last chunk).
+        const int ntaps = (kc1 - kc0) * TAPS;
+        f32x4 areg2[APASS];
+        f32x4 g4r2 = {1.f, 1.f, 1.f, 1.f}, b4r2 = {0.f, 0.f, 0.f, 0.f};
+        bool ident2 = false;
+        const float* Acur = Abuf;
+#define G2_LOAD_FA(slot_, tap_, shift_, rt_)                                                         \
+        {                                                                                            \
+            const unsigned mb_ = (am[(rt_) / 3] >> (9 * ((rt_) % 3) + (tap_))) & 1u;                 \
+            const int o_ = mb_ ? aoff0 + WIDE_ROWOFF(rt_) * LDK + (shift_) : zoff;                   \
+            fat[slot_][0] = *reinterpret_cast<const f16x8*>(Acur + o_);                              \
+            fat[slot_][1] = *reinterpret_cast<const f16x8*>(Acur + o_ + 16);                         \
+        }
+        TAP_LOAD_B(0, kc0, 0)
+        WIDE_LOAD_A_(kc0, areg, g4r, b4r, ident)
+        WIDE_LOAD_A_(min(kc0 + 1, kc1 - 1), areg2, g4r2, b4r2, ident2)
+        WIDE_STAGE_A_(areg, g4r, b4r, ident, Abuf)
+        WIDE_STAGE_A_(areg2, g4r2, b4r2, ident2, Abuf + QZ * LDK)
+        __syncthreads();
+        WIDE_STAMP(2)
+        G2_LOAD_FA(0, TAP_BIT(0), TAP_SHIFT(0), 0)
+        int chunk = kc0, tap = 0;
+        for (int tt = 0; tt < ntaps; tt += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                int ntap = tap + 1, nchunk = chunk;
+                if (ntap == TAPS) { ntap = 0; nchunk = chunk + 1; }
+                const bool have_next = (tt + half + 1 < ntaps);
+                const bool next_C = have_next && (ntap == 0);                       // the next tap opens a chunk ...
+                const bool next_A = next_C && (((nchunk - kc0) & 1) == 0);          // ... that needs a hand-over
+                TAP_LOAD_B(1 - half, (have_next ? nchunk : chunk), (have_next ? ntap : tap))
+                const int sh = TAP_SHIFT(tap), nsh = TAP_SHIFT(ntap), tb = TAP_BIT(tap), ntb = TAP_BIT(ntap);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (rt + 1 < RT) { G2_LOAD_FA((rt + 1) & 1, tb, sh, rt + 1) }
+                    else if (have_next && !next_C) { G2_LOAD_FA(0, ntb, nsh, 0) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!dbg_no_mfma) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][0], fbt[half][c][0], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][0], fbt[half][c][1], acc[rt][c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fat[rt & 1][1], fbt[half][c][0], acc[rt][c], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (next_A && !dbg_no_aload) {
+                    WIDE_LOAD_A_(nchunk, areg, g4r, b4r, ident)                     // both in flight across the barrier
+                    WIDE_LOAD_A_(min(nchunk + 1, kc1 - 1), areg2, g4r2, b4r2, ident2)
+                    __syncthreads();                // every wave is done reading both sub-slabs
+                    WIDE_STAGE_A_(areg, g4r, b4r, ident, Abuf)
+                    WIDE_STAGE_A_(areg2, g4r2, b4r2, ident2, Abuf + QZ * LDK)
+                    __syncthreads();
+                    Acur = Abuf;
+                    G2_LOAD_FA(0, TAP_BIT(0), TAP_SHIFT(0), 0)
+                } else if (next_C) {
+                    Acur = Abuf + (dbg_no_aload ? 0 : ((nchunk - kc0) & 1) * QZ * LDK);      // the chunk staged with its predecessor
+                    G2_LOAD_FA(0, TAP_BIT(0), TAP_SHIFT(0), 0)
+                }
+                tap = ntap;
+                chunk = nchunk;
+            }
+        }
+#undef G2_LOAD_FA
         } else {
         const int ntaps = (kc1 - kc0) * TAPS;
         TAP_LOAD_B(0, kc0, 0)
@@ -943,7 +1021,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef WIDE_ROWOFF
 }
 
-template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false, bool TWO = false, bool WP = false>
+template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false, bool TWO = false, bool WP = false, bool G2 = false>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = (4 / WN) * RT * 16, N_T = WN * 32 * NT, NTHR = 256;
     constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 9) ? 128 : (APASS <= 10) ? 64 : 32;
@@ -952,13 +1030,13 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);
-    constexpr int LDK = WidePitch<W2, PIPE, WP>::value;
+    constexpr int LDK = WidePitch<W2, PIPE, WP || G2>::value;
     if (PIPE && a.taps != 9) return hipErrorInvalidValue;
     if (WP && (a.taps != 9 || a.W != 4 || a.HW % 16 != 0)) return hipErrorInvalidValue;
-    size_t lds = (size_t)((DB ? 2 : 1) * (QA + 2) * LDK + 2 * NS) * sizeof(float);
+    size_t lds = (size_t)(((DB || G2) ? 2 : 1) * (QA + 2) * LDK + 2 * NS) * sizeof(float);
     lds = std::max(lds, (size_t)((M_T / (W2 ? 2 : WP ? RT / 4 : WIDE_NH)) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE, TWO, WP>;
+    auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE, TWO, WP, G2>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     const int n_mtiles = (a.M + M_T - 1) / M_T;
     if (a.ksplit > 1 && a.K % 64 != 0) return hipErrorInvalidValue;          // split-K walks even chunk ranges
@@ -1035,7 +1113,18 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, true>(a, g, s);
         return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, true>(a, g, s);
     }
+    // Two chunks per slab hand-over (G2) on the 64-row-per-wave tap loops: measured and NOT used (opt-in: SPDM_G2=1).  Same box,
+    // traced, B = 4096: the 128 x 128 tiles of levels 2-3 are unchanged within 1-2 us per launch (16 launches, 35-100 us each);
+    // the 64-wide 256 x 64 tiles get SLOWER (inc.b 289 -> 311, up3.dc2a 462 -> 482, up3.dc2b 303 -> 310 us: 24-76 bytes of
+    // scratch and the 144-byte pitch).  So the global-load round trip is not what a hand-over costs -- the transform (GroupNorm,
+    // GELU, split), its LDS writes and the barrier pair are, and they scale with the bytes staged.
+    const bool g2 = a.K >= 64 && (a.sw & SW_G2);
     if (g.m_tile == 128) {
+        if (g2) {
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, false, false, true>(a, g, s);
+            if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, false, false, true>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 2, false, false, false, true>(a, g, s);
+        }
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4>(a, g, s);
         return launch_wide_cfg<2, PRO_GN_GELU, false, 4>(a, g, s);
@@ -1060,6 +1149,11 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
             if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 1, true>(a, g, s);
             if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 1, true>(a, g, s);
             return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 1, true>(a, g, s);
+        }
+        if (g2) {
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 1, false, false, false, true>(a, g, s);
+            if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 1, false, false, false, true>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 1, false, false, false, true>(a, g, s);
         }
         if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 1>(a, g, s);
         if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 1>(a, g, s);

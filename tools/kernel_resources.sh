@@ -13,5 +13,5 @@ for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S
     import subprocess
     dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     dem = dem.replace("spdm::", "").replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-    print(f"{dem[:60]:60s} next_free_vgpr {g('next_free_vgpr'):>4s} accum_offset {g('accum_offset'):>4s} scratch {g('private_segment_fixed_size'):>5s} sgpr {g('next_free_sgpr'):>4s}")
+    print(f"{dem[:72]:72s} next_free_vgpr {g('next_free_vgpr'):>4s} accum_offset {g('accum_offset'):>4s} scratch {g('private_segment_fixed_size'):>5s} sgpr {g('next_free_sgpr'):>4s}")
 PY
