@@ -881,9 +881,17 @@ static bool uses_wp4(const GemmArgs& a0, const GemmGeom& g) {
     a.ksplit = g.ksplit;
     return conv_wide_supported(a, g);
 }
+// ... width-8 maps on the class-major variants (256-row tiles): 44 of 48
+static bool uses_wp8(const GemmArgs& a0, const GemmGeom& g) {
+    if (!(a0.split && a0.taps == 9 && a0.W == 8 && g.n_tile == 128 && g.m_tile == 256 && a0.HW % 32 == 0 && a0.K % 64 == 0 &&
+          !(a0.sw & SW_NO_WP8)) || g.skinny) return false;
+    GemmArgs a = a0;
+    a.ksplit = g.ksplit;
+    return conv_wide_supported(a, g);
+}
 double gemm_flops(const GemmArgs& a) {
     const GemmGeom g = gemm_geometry(a.geom_M > 0 ? a.geom_M : a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS);
-    const double taps = uses_w2(a, g) ? 6.0 : uses_wp4(a, g) ? 7.5 : (double)a.taps;
+    const double taps = uses_w2(a, g) ? 6.0 : uses_wp4(a, g) ? 7.5 : uses_wp8(a, g) ? 8.25 : (double)a.taps;
     return 2.0 * (double)a.M * (double)a.N * (double)a.K * taps;
 }
 

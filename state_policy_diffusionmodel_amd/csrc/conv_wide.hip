@@ -118,7 +118,7 @@ __device__ __forceinline__ f32x2 split2(float a, float b) {
 // G2 (experiment, opt-in SPDM_G2=1; see launch_conv_wide for the measurement): two 32-channel chunks per slab hand-over on the
 // 64-row-per-wave variants of the tap loop -- the loads of both chunks in flight together, one round trip and one barrier pair
 // per 64 channels.  Neutral to slower: the round trip is not what the hand-over costs.
-template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE, bool TWO = false, bool WP = false, bool G2 = false>
+template <int NT, int PRO, bool W2, int RT, int WN, bool PIPE, bool TWO = false, int WP = 0, bool G2 = false>
 // launch bound (256, 2): a 256-register budget.  The 8 x 2 variants with a prologue then carry 88-128 bytes of scratch per lane
 // (stats finalisation state parked across the main loop); with (256, 1) the compiler allocates 203-250 registers and no scratch,
 // but schedules the loop worse: measured 10.5 vs 9.6-9.9 ms per step (same box, alternating).  Keep 2.
@@ -143,7 +143,16 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     static_assert(RT == 8 || (RT == 4 && NT == 2 && !W2), "64-row waves only in the tap-pair loop");
     static_assert(WN == 2 || (WN == 1 && RT == 4), "the 4 x 1 wave arrangement uses 64-row waves");
     static_assert(!TWO || (!PIPE && PRO != PRO_GN_GELU), "two-source input: first conv of a block, plain hand-over");
-    static_assert(!WP || (NT == 2 && WN == 2 && !W2 && !PIPE), "width-4 row permutation: 128-wide tiles, tap loop");
+    static_assert(WP == 0 || WP == 4 || WP == 8, "row permutation for width-4 or width-8 maps");
+    static_assert(!WP || (NT == 2 && WN == 2 && !W2 && !PIPE), "row permutation: 128-wide tiles");
+    static_assert((16 + 4 * (WP == 8 ? 7 : 6)) % 4 == 0, "A ring phase");
+    static_assert(WP != 8 || RT == 8, "width-8 maps: one 128-row block per wave");
+    constexpr bool WP8 = (WP == 8);
+    // WP8: CLASS-MAJOR slab.  Slab row q (image position m0 - halo + q, halo = 9) has class c = (q + 7) % 8 = its w and index
+    // i = (q + 7) / 8; it is stored at LDS row c NI8 + i.  A row tile (one class, 16 consecutive indices) then reads 16
+    // CONSECUTIVE LDS rows, and a tap (dh, dw) is the uniform shift dw NI8 + dh -- in the natural layout the stride-8 fragment
+    // read would be 4-way bank-conflicted at any 16-byte-aligned pitch and the LDS array would become the bound.
+    constexpr int NI8 = (M_T + 18 + 6) / 8 + 1;
     static_assert(!G2 || (NT == 2 && RT == 4 && !W2 && !PIPE && !WP && !WIDE_DB), "two chunks per hand-over: the plain tap loop, 64 rows per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     const int HW = a.HW, W = a.W, H = a.H, M = a.M, K = a.K, N = a.N;
     const int halo = W + 1;
     const int QA = M_T + 2 * halo;
-    const int QZ = QA + 2;                    // + the all-zero row (masked taps read it) + a dump row
+    const int QZ = WP8 ? 8 * NI8 + 2 : QA + 2;  // + the all-zero row (masked taps read it) + a dump row
 
     // ---- tile of this workgroup (XCD-aware, bijective remap: the n-tiles of an m-tile share an XCD's L2) ----
     const int n_ntiles = N / N_T;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     const int kc0 = 2 * (int)((long long)ks * (K / (2 * CK)) / ksp), kc1 = (ksp > 1) ? 2 * (int)((long long)(ks + 1) * (K / (2 * CK)) / ksp) : K / CK;
 
     static_assert(!PIPE || (NT == 2 && !W2), "the pipelined hand-over exists in the tap loop of 128-wide tiles");
-    constexpr int LDK = WidePitch<W2, PIPE, WP || G2>::value;        // (shadows the namespace constant: every macro below uses it)
+    constexpr int LDK = WidePitch<W2, PIPE, (WP != 0) || G2>::value; // (shadows the namespace constant: every macro below uses it)
     constexpr bool PERM = WIDE_LDS_PERM && !W2 && !PIPE && !WP && !G2;
     constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);       // (the other loops keep the single slab)
     float* Abuf = smem;                       // [QZ][LDK]: the slab the MFMA loop reads
@@ -194,7 +203,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     constexpr bool dbg_no_mfma = false, dbg_no_wload = false, dbg_no_aload = false;     // ablation knobs exist in diagnostic builds only
 #endif
     WIDE_STAMP(1)
-    if (tid < LDK) { Abuf[QA * LDK + tid] = 0.f; Awr[QA * LDK + tid] = 0.f; }
+    const int zrow = WP8 ? 8 * NI8 : QA;        // the all-zero row; zrow + 1: the dump row
+    if (tid < LDK) { Abuf[zrow * LDK + tid] = 0.f; Awr[zrow * LDK + tid] = 0.f; }
     if (G2 && tid < LDK) Abuf[(QZ + QA) * LDK + tid] = 0.f;         // the all-zero row of the second chunk's sub-slab
 
     constexpr bool pro = (PRO != PRO_NONE);
@@ -236,10 +246,11 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     // ---- A operand of row tile rt: lane (l16, kg) reads 16 bytes (8 fp16 of k = 8 kg ..) of slab row
     //      halo + wm 128 + ROWOFF(rt) + rowlane.  W2: rows permuted by parity (even tiles w = 0, odd tiles w = 1).
     //      The 9 tap-validity bits of each of the 8 tiles are packed three tiles to a register. ----
-#define WIDE_ROWOFF(rt_) (W2 ? (((rt_) >> 1) * 32 + ((rt_) & 1)) : WP ? (((rt_) >> 2) * 64 + ((rt_) & 3)) : (rt_) * 16)
-    const int rowlane = W2 ? 2 * l16 : WP ? 4 * l16 : PERM ? (l16 < 4 ? l16 : l16 < 12 ? l16 + 4 : l16 - 8) : l16;
-    const int aoff0 = (wm * RW + rowlane + halo) * LDK + kg * 4;
-    const int zoff = QA * LDK + kg * 4;
+#define WIDE_ROWOFF(rt_) (W2 ? (((rt_) >> 1) * 32 + ((rt_) & 1)) : WP8 ? (rt_) : WP ? (((rt_) >> 2) * 64 + ((rt_) & 3)) : (rt_) * 16)
+#define WIDE_LDSOFF(rt_) (WP8 ? (rt_) * NI8 : WIDE_ROWOFF(rt_))      /* LDS row offset of row tile rt_ from the lane's base row */
+    const int rowlane = W2 ? 2 * l16 : WP ? WP * l16 : PERM ? (l16 < 4 ? l16 : l16 < 12 ? l16 + 4 : l16 - 8) : l16;
+    const int aoff0 = WP8 ? (2 + wm * 16 + l16) * LDK + kg * 4 : (wm * RW + rowlane + halo) * LDK + kg * 4;
+    const int zoff = zrow * LDK + kg * 4;
     unsigned am[(RT + 2) / 3] = {};
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -322,7 +333,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
             if (!((avalid >> p_) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                              \
             const f32x2 p0_ = split2(v_.x, v_.y), p1_ = split2(v_.z, v_.w);                          \
             {   /* rows past the slab go to a dump row: no branch (see the header) */                 \
-                float* row_ = (dst_) + min(p_ * RP + srow_o, QA + 1) * LDK;                             \
+                const int q_ = p_ * RP + srow_o;                                                     \
+                float* row_ = (dst_) + (WP8 ? (q_ < QA ? ((q_ + 7) & 7) * NI8 + ((q_ + 7) >> 3) : 8 * NI8 + 1) : min(q_, QA + 1)) * LDK; \
                 *reinterpret_cast<f32x2*>(row_ + c4 * 2) = f32x2{p0_.x, p1_.x};       /* hi */       \
                 *reinterpret_cast<f32x2*>(row_ + 16 + c4 * 2) = f32x2{p0_.y, p1_.y};  /* lo */       \
             }                                                                                        \
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #define WIDE_LOAD_FA(slot_, tap_, shift_, rt_)                                                       \
     {                                                                                                \
         const unsigned mb_ = (am[(rt_) / 3] >> (9 * ((rt_) % 3) + (tap_))) & 1u;                     \
-        const int o_ = mb_ ? aoff0 + WIDE_ROWOFF(rt_) * LDK + (shift_) : zoff;                       \
+        const int o_ = mb_ ? aoff0 + WIDE_LDSOFF(rt_) * LDK + (shift_) : zoff;                       \
         fa[slot_][0] = *reinterpret_cast<const f16x8*>(Abuf + o_);                                   \
         fa[slot_][1] = *reinterpret_cast<const f16x8*>(Abuf + o_ + 16);                              \
     }
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
     const int nrows = (kc1 - kc0) * 3;        // loop trips: one kernel row (3 taps) of one chunk each
     f16x8 fa[FAR][2], fb[FBR][2][2];
     // slab-row shift (floats) of tap (kernel row kr_, column index dwi_ = dw + 1)
-#define WIDE_SHIFT(kr_, dwi_) ((((kr_) - 1) * W + ((dwi_) - 1)) * LDK)
+#define WIDE_SHIFT(kr_, dwi_) (WP8 ? (((dwi_) - 1) * NI8 + ((kr_) - 1)) * LDK : (((kr_) - 1) * W + ((dwi_) - 1)) * LDK)
 
     if constexpr (!W2 && NT == 2 && !(WP && RT == 8)) {
         // 128-wide tiles: one tap at a time with ALL four column tiles of the tap's weights in registers (two tap
@@ -694,8 +706,10 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         // Row tile rt holds the positions w = rt % 4 of its 64-row block.  Kernel row = 6 phases: centre tap on all 8 row tiles
         // (x 2 column pairs), dw = +1 on the six tiles with w < 3, dw = -1 on the six with w > 0: 40 tile steps instead of 48.
         //   step q:  0..15 centre   16..27 (+1: tiles 0 1 2 4 5 6, pair 0 / 1)   28..39 (-1: tiles 1 2 3 5 6 7, pair 0 / 1)
-#define WP_PLUS(i_) ((i_) + (i_) / 3)
-#define WP_MINUS(i_) ((i_) + (i_) / 3 + 1)
+#define WP_PLUS(i_) (WP8 ? (i_) : (i_) + (i_) / 3)
+#define WP_MINUS(i_) (WP8 ? (i_) + 1 : (i_) + (i_) / 3 + 1)
+        constexpr int WS = WP8 ? 7 : 6;                 // tiles a side column visits (W2: 4)
+        constexpr int Q1 = 16 + 2 * WS, Q2 = 16 + 4 * WS;     // first step of the dw = -1 phases; steps per kernel row (40 | 44: both = 0 mod FAR)
         WIDE_LOAD_B(0, kc0, 1, 0)
         WIDE_LOAD_A(kc0)
         WIDE_STAGE_A()
@@ -729,10 +743,10 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
             for (int cp = 0; cp < 2; ++cp) {
                 if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3 + 2, 1) } else { WIDE_LOAD_B(0, chunk, kr * 3, 0) }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int q = 16 + cp * 6 + i;
-                    if (q + 2 < 28) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 2, WIDE_SHIFT(kr, 2), WP_PLUS((q + 2 - 16) % 6)) }
-                    else { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), WP_MINUS(q + 2 - 28)) }
+                for (int i = 0; i < WS; ++i) {
+                    const int q = 16 + cp * WS + i;
+                    if (q + 2 < Q1) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3 + 2, WIDE_SHIFT(kr, 2), WP_PLUS((q + 2 - 16) % WS)) }
+                    else { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), WP_MINUS(q + 2 - Q1)) }
                     __builtin_amdgcn_sched_barrier(0);
                     WIDE_STEP(q % FAR, cp, WP_PLUS(i), cp * 2)
                     __builtin_amdgcn_sched_barrier(0);
@@ -743,10 +757,10 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
             for (int cp = 0; cp < 2; ++cp) {
                 if (cp == 0) { WIDE_LOAD_B(1, chunk, kr * 3, 1) } else { WIDE_LOAD_B(0, bchunk, bkr * 3 + 1, 0) }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int q = 28 + cp * 6 + i;
-                    if (q + 2 < 40) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), WP_MINUS((q + 2 - 28) % 6)) }
-                    else if (have_next && !next_A) { WIDE_LOAD_FA((q + 2) % FAR, nkr * 3 + 1, WIDE_SHIFT(nkr, 1), q + 2 - 40) }
+                for (int i = 0; i < WS; ++i) {
+                    const int q = Q1 + cp * WS + i;
+                    if (q + 2 < Q2) { WIDE_LOAD_FA((q + 2) % FAR, kr * 3, WIDE_SHIFT(kr, 0), WP_MINUS((q + 2 - Q1) % WS)) }
+                    else if (have_next && !next_A) { WIDE_LOAD_FA((q + 2) % FAR, nkr * 3 + 1, WIDE_SHIFT(nkr, 1), q + 2 - Q2) }
                     __builtin_amdgcn_sched_barrier(0);
                     WIDE_STEP(q % FAR, cp, WP_MINUS(i), cp * 2)
                     __builtin_amdgcn_sched_barrier(0);
@@ -920,7 +934,8 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
         // the lane's four registers are one 4-row unit (W2: rows 2 apart inside one 8-row block -> slot unit
         // 2 (block) + parity; a sample is still a contiguous run of HW / 4 slot units because HW % 8 == 0)
         // WP: rows 4 apart inside one 16-row span -> slot unit 4 (span) + class; HW % 16 == 0 keeps a sample's units contiguous
-        const int unit = wm * (RW / 4) + (W2 ? (rt >> 1) * 8 + 2 * kg + (rt & 1) : WP ? (rt >> 2) * 16 + 4 * kg + (rt & 3) : rt * 4 + rb4);
+        // (WP8: rows 8 apart inside one 32-row span -> unit 8 (span) + class; HW % 32 == 0)
+        const int unit = wm * (RW / 4) + (W2 ? (rt >> 1) * 8 + 2 * kg + (rt & 1) : WP8 ? 8 * kg + rt : WP ? (rt >> 2) * 16 + 4 * kg + (rt & 3) : rt * 4 + rb4);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -941,6 +956,21 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         if (h) __syncthreads();
+        if constexpr (WP8) {
+            // every row tile spans the wave's 128 rows (rows 8 (4 kg + j) + rt): the half h = rows [64 h, 64 h + 64) is what the
+            // lanes with kg >> 1 == h hold, of ALL eight tiles
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int col_l = wn * NT * 32 + ct * 16 + l16;
+                    if ((kg >> 1) == h) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            otile[(wm * (RW / NH) + 8 * (4 * (kg & 1) + j) + rt) * N_T + col_l] = acc[rt][ct][j];
+                    }
+                }
+        } else
 #pragma unroll
         for (int rq = 0; rq < RT / NH; ++rq) {
             const int rt = (RT / NH) * h + rq;
@@ -1021,7 +1051,7 @@ __global__ __launch_bounds__(256, WIDE_MINB) void conv3x3_wide_kernel(const Gemm
 #undef WIDE_ROWOFF
 }
 
-template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false, bool TWO = false, bool WP = false, bool G2 = false>
+template <int NT, int PRO, bool W2 = false, int RT = 8, int WN = 2, bool PIPE = false, bool TWO = false, int WP = 0, bool G2 = false>
 hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     constexpr int M_T = (4 / WN) * RT * 16, N_T = WN * 32 * NT, NTHR = 256;
     constexpr int APASS = (M_T + 18 + 31) / 32, NSMAX = (APASS <= 9) ? 128 : (APASS <= 10) ? 64 : 32;
@@ -1030,10 +1060,11 @@ hipError_t launch_wide_cfg(const GemmArgs& a, const GemmGeom& g, hipStream_t s) 
     const int NS = (((QA - 1) / a.HW + 2) + 3) & ~3;
     if (NS > NSMAX || g.m_tile != M_T || g.n_tile != N_T) return hipErrorInvalidValue;
     constexpr bool DB = PIPE || (WIDE_DB && (NT == 2) && !W2);
-    constexpr int LDK = WidePitch<W2, PIPE, WP || G2>::value;
+    constexpr int LDK = WidePitch<W2, PIPE, (WP != 0) || G2>::value;
     if (PIPE && a.taps != 9) return hipErrorInvalidValue;
-    if (WP && (a.taps != 9 || a.W != 4 || a.HW % 16 != 0)) return hipErrorInvalidValue;
-    size_t lds = (size_t)(((DB || G2) ? 2 : 1) * (QA + 2) * LDK + 2 * NS) * sizeof(float);
+    if (WP && (a.taps != 9 || a.W != WP || a.HW % (4 * WP) != 0)) return hipErrorInvalidValue;
+    const int QZ = (WP == 8) ? 8 * ((M_T + 18 + 6) / 8 + 1) + 2 : QA + 2;          // (WP8: the class-major slab)
+    size_t lds = (size_t)(((DB || G2) ? 2 : 1) * QZ * LDK + 2 * NS) * sizeof(float);
     lds = std::max(lds, (size_t)((M_T / (W2 ? 2 : WP ? RT / 4 : WIDE_NH)) * N_T + (M_T / 4) * WN * 2) * sizeof(float));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = conv3x3_wide_kernel<NT, PRO, W2, RT, WN, PIPE, TWO, WP, G2>;
@@ -1086,20 +1117,30 @@ hipError_t launch_conv_wide(const GemmArgs& a, const GemmGeom& g, hipStream_t s)
         const bool two = a.skip != nullptr;
         if (g.m_tile == 128) {
             if (two) {
-                if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, true, true>(a, g, s);
-                return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, true, true>(a, g, s);
+                if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, true, 4>(a, g, s);
+                return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, true, 4>(a, g, s);
             }
-            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, false, true>(a, g, s);
-            if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, false, true>(a, g, s);
-            return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 2, false, false, true>(a, g, s);
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 4, 2, false, false, 4>(a, g, s);
+            if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 4, 2, false, false, 4>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN_GELU, false, 4, 2, false, false, 4>(a, g, s);
         }
         if (two) {
-            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, true, true>(a, g, s);
-            return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, true, true>(a, g, s);
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, true, 4>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, true, 4>(a, g, s);
         }
-        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, false, true>(a, g, s);
-        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, false, true>(a, g, s);
-        return launch_wide_cfg<2, PRO_GN_GELU, false, 8, 2, false, false, true>(a, g, s);
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, false, 4>(a, g, s);
+        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, false, 4>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN_GELU, false, 8, 2, false, false, 4>(a, g, s);
+    }
+    // width-8 maps (level 0), 256-row tiles: the same with eight classes on a class-major slab (44 of 48 tile steps per kernel row)
+    if (a.W == 8 && a.taps == 9 && g.n_tile == 128 && g.m_tile == 256 && a.HW % 32 == 0 && a.K % 64 == 0 && !(a.sw & SW_NO_WP8)) {
+        if (a.skip != nullptr) {
+            if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, true, 8>(a, g, s);
+            return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, true, 8>(a, g, s);
+        }
+        if (a.pro == PRO_NONE) return launch_wide_cfg<2, PRO_NONE, false, 8, 2, false, false, 8>(a, g, s);
+        if (a.pro == PRO_GN) return launch_wide_cfg<2, PRO_GN, false, 8, 2, false, false, 8>(a, g, s);
+        return launch_wide_cfg<2, PRO_GN_GELU, false, 8, 2, false, false, 8>(a, g, s);
     }
     if (a.skip != nullptr) {        // two-source input: the three 128-wide configurations
         if (g.m_tile == 128) {

@@ -40,7 +40,10 @@ def test_gemm_configurations_agree_with_exact_fp32_path():
         # width-4 maps on the row-permuted conv_wide variants (WP): 256-row tiles (phase loop) and 128-row tiles (unrolled taps),
         # every prologue, ragged last tiles, a sample length that is not a power of two (HW = 48)
         (2048, 16, 4, 128, 128, 9, 1, 0), (2048, 16, 4, 128, 128, 9, 2, 0), (1500, 16, 4, 256, 256, 9, 0, 0), (600, 16, 4, 128, 128, 9, 2, 0),
-        (333, 16, 4, 256, 256, 9, 1, 0), (700, 12, 4, 128, 128, 9, 2, 0), (2047, 12, 4, 128, 256, 9, 1, 0), (512, 32, 8, 64, 64, 9, 2, 0), (700, 16, 4, 64, 64, 9, 1, 0), (4, 16, 4, 64, 256, 9, 1, 0), (16, 8, 2, 256, 128, 9, 2, 0),
+        (333, 16, 4, 256, 256, 9, 1, 0), (700, 12, 4, 128, 128, 9, 2, 0), (2047, 12, 4, 128, 256, 9, 1, 0),
+        # width-8 maps on the class-major variants (WP8, 256-row tiles): every prologue, a tile that straddles samples (HW = 192)
+        (600, 32, 8, 128, 128, 9, 0, 0), (600, 32, 8, 128, 128, 9, 1, 0), (600, 32, 8, 128, 128, 9, 2, 0), (701, 24, 8, 128, 128, 9, 2, 0),
+        (300, 64, 8, 128, 256, 9, 1, 0), (512, 32, 8, 64, 64, 9, 2, 0), (700, 16, 4, 64, 64, 9, 1, 0), (4, 16, 4, 64, 256, 9, 1, 0), (16, 8, 2, 256, 128, 9, 2, 0),
         (64, 4, 1, 256, 512, 3, 2, 0), (40, 5, 2, 64, 64, 9, 1, 0), (33, 8, 2, 128, 256, 9, 0, 0), (3, 5, 1, 64, 64, 3, 1, 0), (1, 8, 8, 64, 64, 9, 0, 0),
         (8, 32, 8, 64, 192, 1, 0, 1), (8, 32, 8, 64, 64, 1, 0, 3), (8, 16, 4, 128, 128, 1, 0, 2), (5, 1, 1, 1376, 256, 1, 0, 1),
     ]
