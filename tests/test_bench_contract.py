@@ -38,3 +38,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
+
+
+def test_traffic_summary_is_found_by_geometry():
+    """`roofline.traffic` / `hbm_*` come from the committed PMC summaries; bench.py must pick the file whose recorded geometry is
+    the run's (one hard-coded file name), and none for a geometry that was never profiled."""
+    sys.path.insert(0, ROOT)
+    import bench
+    head = bench.find_traffic(4096, 32, 3, True, "ddpm")
+    assert head is not None and head["config"]["horizon"] == 32 and head["traffic_bytes_per_launch"] > 1e8
+    c5 = bench.find_traffic(4096, 64, 6, True, "ddim")
+    assert c5 is not None and c5["config"]["state_dim"] == 6 and c5["hbm_bytes_per_step"] > head["hbm_bytes_per_step"]
+    assert c5["_file"] != head["_file"]
+    assert bench.find_traffic(64, 32, 3, True, "ddpm") is None
+    assert bench.find_traffic(4096, 32, 3, False, "ddpm") is None        # the no-attention model was not profiled
