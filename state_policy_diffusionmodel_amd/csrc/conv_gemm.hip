@@ -733,7 +733,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
 // those would leave CUs idle (small batches / coarse levels).
 // tuning knobs for experiments (SPDM_TUNE0.. read once per process; defaults = the measured choice)
 int spdm_tune(int idx, int dflt) {
-    constexpr int NT = 16;
+    constexpr int NT = 24;
     static int val[NT];
     static bool have[NT], init = false;
     if (!init) {

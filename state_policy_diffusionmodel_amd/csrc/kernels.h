@@ -57,7 +57,7 @@ enum : unsigned {
     SW_T3_BIG = 1u << 5, SW_NO_SMALL_TPI3 = 1u << 6, SW_WIDE_N64_2X2 = 1u << 7, SW_NO_SA_FUSED = 1u << 8,
     SW_NO_SA_TAIL = 1u << 9, SW_ATTN_VALU = 1u << 10, SW_SA_NO_WLDS = 1u << 11, SW_NO_FILM_FOLD = 1u << 12,
     SW_NO_GRAPH = 1u << 13, SW_NO_SPLITK = 1u << 14, SW_ARENA_TRACE = 1u << 15, SW_NO_WIDE_PIPE = 1u << 16, SW_NO_SKINNY = 1u << 17, SW_DEEP = 1u << 18,
-    SW_NO_FILM_LOCAL = 1u << 19, SW_NO_FUSED_SRC = 1u << 20, SW_FILM_LOCAL = 1u << 21, SW_PIN_GEOMETRY = 1u << 22, SW_NO_WP4 = 1u << 23, SW_G2 = 1u << 24, SW_NO_WP8 = 1u << 25,
+    SW_NO_FILM_LOCAL = 1u << 19, SW_NO_FUSED_SRC = 1u << 20, SW_FILM_LOCAL = 1u << 21, SW_PIN_GEOMETRY = 1u << 22, SW_NO_WP4 = 1u << 23, SW_G2 = 1u << 24, SW_NO_WP8 = 1u << 25, SW_NO_SA_HEAD = 1u << 26, SW_SA_HEAD = 1u << 27,
 };
 struct SwitchName { const char* env; unsigned bit; };
 inline const SwitchName* switch_table(int* n) {
@@ -69,7 +69,8 @@ inline const SwitchName* switch_table(int* n) {
         {"SPDM_NO_GRAPH", SW_NO_GRAPH}, {"SPDM_NO_SPLITK", SW_NO_SPLITK}, {"SPDM_ARENA_TRACE", SW_ARENA_TRACE}, {"SPDM_NO_WIDE_PIPE", SW_NO_WIDE_PIPE}, {"SPDM_NO_SKINNY", SW_NO_SKINNY}, {"SPDM_DEEP", SW_DEEP},
         {"SPDM_NO_FILM_LOCAL", SW_NO_FILM_LOCAL}, {"SPDM_NO_FUSED_SRC", SW_NO_FUSED_SRC},
         {"SPDM_FILM_LOCAL", SW_FILM_LOCAL}, {"SPDM_PIN_GEOMETRY", SW_PIN_GEOMETRY},
-        {"SPDM_NO_WP4", SW_NO_WP4}, {"SPDM_G2", SW_G2}, {"SPDM_NO_WP8", SW_NO_WP8}};
+        {"SPDM_NO_WP4", SW_NO_WP4}, {"SPDM_G2", SW_G2}, {"SPDM_NO_WP8", SW_NO_WP8},
+        {"SPDM_NO_SA_HEAD", SW_NO_SA_HEAD}, {"SPDM_SA_HEAD", SW_SA_HEAD}};
     *n = (int)(sizeof(t) / sizeof(t[0]));
     return t;
 }
@@ -267,6 +268,11 @@ hipError_t launch_sa_tail(int C, const float* o, const float* x, float* out, int
                           const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs = nullptr);
 // may the two kernels evaluate the FiLM coefficients themselves for samples of L rows?  (their LDS row per touched sample)
 bool sa_tail_film_local(int C, int L);
+// LayerNorm + in_proj + attention core in one kernel (att = softmax(q k^T / sqrt d) v per sample and head, heads concatenated):
+// blocks whose 8192 / C-row tile holds whole samples of L tokens
+bool sa_head_supported(int C, int L, unsigned sw);
+hipError_t launch_sa_head(int C, const float* x, float* att, int rows, const float* wf_in, const float* b_in, const float* ln_g,
+                          const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs = nullptr);
 // qkv = LayerNorm(x) W_in^T + b_in of the same blocks (LayerNorm from the row itself)
 hipError_t launch_sa_qkv(int C, const float* x, float* qkv, int rows, const float* wf_in, const float* b_in, const float* ln_g,
                          const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs = nullptr);

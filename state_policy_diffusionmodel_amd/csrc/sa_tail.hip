@@ -452,6 +452,245 @@ __global__ __launch_bounds__(256, 2) void sa_qkv_kernel(const SaQkvArgs a) {
         }
     }
     (void)otile;
+}
+
+// ---- LayerNorm + in_proj + the attention core of the same blocks in ONE kernel (round 3) ----------------------------
+// sa_qkv_kernel wrote q, k, v of every token (3 C floats per row: 403 MB at sa1, B = 4096) and the attention core read them
+// back; both launches sat within 1.3 x of their own HBM floor, so the only traffic left to remove was the round trip itself.
+// Here a workgroup owns TM token rows that are WHOLE samples (TM % L == 0: the host checks) and walks the four heads: per head
+// three small products (TM x d each, d = C / 4) from the normalised slab, q / k / v^T of the head as split-fp16 tiles in LDS
+// (24 KB), scores S = q k^T on the matrix cores over the tile's TM keys with the other samples' keys masked (block-diagonal:
+// at L = 16 or 4 a tile holds 2-8 samples; the masked products are noise next to the memory traffic), softmax on the
+// accumulator layout (a query row = 16 lanes of a DPP row x the key tiles), P through LDS into A-operand order, O = P v.
+// Only the head outputs (C floats per row) leave the kernel.  Same split-fp16 scheme and scales as attention.hip
+// (q, k, v x 16, p x 1024, hi*hi + hi*lo + lo*hi, fp32 accumulate); replaces models/Unet_FiLmLayer.py:76-79 for these blocks.
+struct SaHeadArgs {
+    const float* x; float* att; int M;          // [M][C] -> [M][C] (heads concatenated, before out_proj)
+    const float* wf;                            // fragment-order split in_proj weight (3 C x C)
+    const float *b_in, *ln_g, *ln_b;
+    const float* ab; int L;                     // optional FiLM-tail coefficients, as in SaTailArgs; L = tokens per sample
+    FilmSpec fs;
+};
+
+__device__ __forceinline__ float row16_max_dpp(float v) {
+#define DPP_MAX(ctrl_) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, false)));
+    DPP_MAX(0xB1) DPP_MAX(0x4E) DPP_MAX(0x141) DPP_MAX(0x140)
+#undef DPP_MAX
+    return v;
+}
+__device__ __forceinline__ float head_exp_neg(float x) {      // exp(x), x <= 0, through v_exp_f32 with a compensated argument
+    const float t = x * 1.44269504f;
+    const float tl = __fmaf_rn(x, 1.44269504f, -t) + x * 1.925963033e-8f;
+    return __builtin_amdgcn_exp2f(t) * (1.0f + tl * 0.69314718f);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void sa_head_kernel(const SaHeadArgs a) {
+    using S = TailShape<C>;
+    constexpr int T_C = C, T_M = S::TM, NCH = S::NCH, RPP = S::RPP, TPR = S::TPR;
+    constexpr int NP = S::NP;
+    constexpr int D = C / 4;                            // head dimension: 32 | 64
+    constexpr int QROW = 2 * D + 8;                     // halfs per row of the q / k tiles of a head: [D hi | D lo] + 16 bytes
+    constexpr int VROW = 2 * T_M + 8;                   // halfs per row of v^T [D rows] and of P [TM rows]: [TM hi | TM lo] + 16 bytes
+    constexpr int NKT = T_M / 16;                       // key tiles of the scores (4 | 2)
+    constexpr int NDT = D / 16;                         // 16-column tiles of the head output (2 | 4)
+    static_assert(T_M * VROW <= 2 * T_M * QROW, "P aliases the q / k tiles");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int M = a.M, L = a.L;
+    const int m0 = blockIdx.x * T_M;
+    float* Abuf = smem;                                                     // [NCH][TM][T_LDK]: LayerNorm(x), split
+    _Float16* Qs = reinterpret_cast<_Float16*>(smem + NCH * T_M * T_LDK);   // [TM][QROW]
+    _Float16* Ks = Qs + T_M * QROW;                                         // [TM][QROW]
+    _Float16* Vt = Ks + T_M * QROW;                                         // [D][VROW]
+    _Float16* Ps = Qs;                                                      // [TM][VROW]: once the scores are in registers
+    const int c16 = tid % TPR, srow0 = tid / TPR;
+
+    // ---- slab <- LayerNorm(x) (the head of sa_qkv_kernel) ----
+    {
+        tf32x4 v[NP];
+        const tf32x4 g4 = *reinterpret_cast<const tf32x4*>(a.ln_g + c16 * 4);
+        const tf32x4 b4 = *reinterpret_cast<const tf32x4*>(a.ln_b + c16 * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = min(m0 + RPP * i + srow0, M - 1);
+            v[i] = *reinterpret_cast<const tf32x4*>(a.x + (size_t)row * T_C + c16 * 4);
+        }
+        if (a.ab != nullptr) tail_film_fold<C>(v, a.ab, a.L, m0, M, c16, srow0);
+        if (a.fs.on) {
+            float* abl = reinterpret_cast<float*>(Qs);           // (dead until the first head's tiles are written)
+            tail_film_rows<C>(a.fs, a.L, m0, M, wave, lane, abl);
+            __syncthreads();
+            tail_film_fold_lds<C>(v, abl, a.L, m0, M, c16, srow0);
+            __syncthreads();
+        }
+        float part[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = trow_sum<TPR>(part[i]);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float mean = part[i] * (1.0f / (float)C);
+            const tf32x4 t = v[i];
+            const tf32x4 d = {t.x - mean, t.y - mean, t.z - mean, t.w - mean};
+            v[i] = d;
+            part[i] = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = trow_sum<TPR>(part[i]);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float rstd = __builtin_amdgcn_rsqf(part[i] * (1.0f / (float)C) + 1e-5f);
+            const tf32x4 d = v[i];
+            v[i] = tf32x4{d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w};
+        }
+        TAIL_WRITE_SLAB(v)
+    }
+    __syncthreads();
+
+    // product tile of this wave: 16 rows x 32 columns of a head's q, k or v  (C = 128: 4 row tiles x the head's 32 columns;
+    // C = 256: 2 row tiles x 2 halves of the head's 64 columns)
+    const int rtw = (C == 128) ? wave : (wave >> 1);
+    const int cpw = (C == 128) ? 0 : (wave & 1);
+    const bool attn_wave = wave < NKT;                  // the waves that own 16 query rows (C = 256: two of the four)
+    const float qscale = (D == 32) ? 0.17677669529663687f : 0.125f;         // 1 / sqrt(d)
+    constexpr size_t WCHUNK = (size_t)(3 * C / 16) * 2 * 256;               // floats per 32-channel chunk of the fragment-order in_proj
+
+    // weight fragments of a product: two 16-column tiles x {hi, lo} per 32-channel chunk, double-buffered; the FIRST chunk of the
+    // next product (also across the attention phase, into the next head) is requested during the last chunk of the current one --
+    // twelve products per workgroup each starting with an exposed L2 round trip were a third of the kernel
+    tf16x8 fbw[2][2][2];
+#define HEAD_WPTR(h_, g_) (a.wf + ((size_t)((g_) * (C / 16) + (h_) * (D / 16) + cpw * 2) * 2) * 256 + lane * 4)
+#define HEAD_LOAD_W(slot_, wp_, kc_)                                                                 \
+    _Pragma("unroll") for (int ct_ = 0; ct_ < 2; ++ct_) {                                           \
+        fbw[slot_][ct_][0] = *reinterpret_cast<const tf16x8*>((wp_) + (size_t)(kc_) * WCHUNK + ct_ * 512);        \
+        fbw[slot_][ct_][1] = *reinterpret_cast<const tf16x8*>((wp_) + (size_t)(kc_) * WCHUNK + ct_ * 512 + 256);  \
+    }
+    HEAD_LOAD_W(0, HEAD_WPTR(0, 0), 0)
+    for (int h = 0; h < 4; ++h) {
+        // ---- q, k, v of head h: three TM x d products from the slab ----
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            tf32x4 acc[2] = {tf32x4{0.f, 0.f, 0.f, 0.f}, tf32x4{0.f, 0.f, 0.f, 0.f}};
+            const float* wp = HEAD_WPTR(h, g);
+            const float* wnext = (g < 2) ? HEAD_WPTR(h, g + 1) : HEAD_WPTR(min(h + 1, 3), 0);     // (after the last product: a valid re-read)
+#pragma unroll
+            for (int kc = 0; kc < NCH; ++kc) {
+                if (kc + 1 < NCH) { HEAD_LOAD_W((kc + 1) & 1, wp, kc + 1) } else { HEAD_LOAD_W(0, wnext, 0) }
+                const float* ap = Abuf + (kc * T_M + rtw * 16 + l16) * T_LDK + kg * 4;
+                const tf16x8 a_h = *reinterpret_cast<const tf16x8*>(ap), a_l = *reinterpret_cast<const tf16x8*>(ap + 16);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, fbw[kc & 1][ct][0], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, fbw[kc & 1][ct][1], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, fbw[kc & 1][ct][0], acc[ct], 0, 0, 0);
+                }
+            }
+            // bias (+ 1 / sqrt d on q), x 16, split, into the head's tile: q, k row-major, v transposed
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int col = cpw * 32 + ct * 16 + l16;                    // column inside the head
+                const float bias = a.b_in[g * T_C + h * D + col];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = rtw * 16 + 4 * kg + j;
+                    float val = acc[ct][j] * T_DESCALE + bias;
+                    if (g == 0) val *= qscale;
+                    const float xs = val * T_ACT_SCALE;
+                    const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
+                    if (g == 2) { Vt[col * VROW + row] = hi; Vt[col * VROW + T_M + row] = lo; }
+                    else { _Float16* X = (g == 0) ? Qs : Ks; X[row * QROW + col] = hi; X[row * QROW + D + col] = lo; }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- S = q k^T over the tile's TM keys (this wave's 16 query rows) ----
+        tf32x4 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) sc[kt] = tf32x4{0.f, 0.f, 0.f, 0.f};
+        if (attn_wave) {
+#pragma unroll
+            for (int ks = 0; ks < D / 32; ++ks) {
+                const _Float16* qp = Qs + (wave * 16 + l16) * QROW + 32 * ks + 8 * kg;
+                const tf16x8 q_h = *reinterpret_cast<const tf16x8*>(qp), q_l = *reinterpret_cast<const tf16x8*>(qp + D);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const _Float16* kp = Ks + (kt * 16 + l16) * QROW + 32 * ks + 8 * kg;
+                    const tf16x8 k_h = *reinterpret_cast<const tf16x8*>(kp), k_l = *reinterpret_cast<const tf16x8*>(kp + D);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q_h, k_h, sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q_h, k_l, sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q_l, k_h, sc[kt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                // every wave has its scores: the q / k tiles may be overwritten by P
+
+        // ---- softmax over the keys of the query's own sample; P x 1024, split, into A-operand rows ----
+        if (attn_wave) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wave * 16 + 4 * kg + j;
+                const int smp = row / L;
+                float s[NKT];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const bool own = ((kt * 16 + l16) / L) == smp;
+                    s[kt] = own ? sc[kt][j] * (1.0f / 256.0f) : -3.0e38f;
+                    mx = fmaxf(mx, s[kt]);
+                }
+                mx = row16_max_dpp(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    s[kt] = (s[kt] > -1.0e38f) ? head_exp_neg(s[kt] - mx) : 0.f;
+                    sum += s[kt];
+                }
+                sum = row16_sum_dpp(sum);
+                const float inv = 1024.0f / sum;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const float ps = s[kt] * inv;
+                    const _Float16 hi = (_Float16)ps, lo = (_Float16)(ps - (float)hi);
+                    Ps[row * VROW + kt * 16 + l16] = hi;
+                    Ps[row * VROW + T_M + kt * 16 + l16] = lo;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- O = P v, out of the kernel ----
+        if (attn_wave) {
+            tf32x4 o[NDT];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[dt] = tf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < T_M / 32; ++ks) {
+                const _Float16* pp = Ps + (wave * 16 + l16) * VROW + 32 * ks + 8 * kg;
+                const tf16x8 p_h = *reinterpret_cast<const tf16x8*>(pp), p_l = *reinterpret_cast<const tf16x8*>(pp + T_M);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const _Float16* vp = Vt + (dt * 16 + l16) * VROW + 32 * ks + 8 * kg;
+                    const tf16x8 v_h = *reinterpret_cast<const tf16x8*>(vp), v_l = *reinterpret_cast<const tf16x8*>(vp + T_M);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h, v_h, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h, v_l, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_l, v_h, o[dt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = m0 + wave * 16 + 4 * kg + j;
+                    if (row < M) a.att[(size_t)row * T_C + h * D + dt * 16 + l16] = o[dt][j] * (1.0f / 16384.0f);
+                }
+        }
+        __syncthreads();                                // the head's tiles are free for the next head
+    }
 #undef TAIL_LOAD_B
 #undef TAIL_LOAD_FA
 #undef TAIL_WRITE_SLAB
@@ -495,6 +734,30 @@ hipError_t launch_sa_tail(int C, const float* o, const float* x, float* out, int
                        + (fs ? (size_t)film_rows_cap(TM, L) * 2 * C * sizeof(float) : 0);
     if (C == 128) hipLaunchKernelGGL(sa_tail_kernel<128>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(sa_tail_kernel<256>, dim3((rows + TM - 1) / TM), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// Which blocks run LayerNorm + in_proj + attention core as ONE kernel: the tile of 8192 / C rows must hold whole samples
+bool sa_head_supported(int C, int L, unsigned sw) {
+    return (C == 128 || C == 256) && L >= 1 && (8192 / C) % L == 0 && !(sw & (SW_NO_SA_TAIL | SW_NO_SA_HEAD));
+}
+
+hipError_t launch_sa_head(int C, const float* x, float* att, int rows, const float* wf_in, const float* b_in, const float* ln_g,
+                          const float* ln_b, const float* ab, int L, hipStream_t s, const FilmSpec* fs) {
+    if (rows <= 0 || !x || !att || !wf_in || !b_in || !ln_g || !ln_b || !sa_head_supported(C, L, 0) || rows % L != 0) return hipErrorInvalidValue;
+    if (fs && (ab || !sa_tail_film_local(C, L) || fs->C != C)) return hipErrorInvalidValue;
+    SaHeadArgs a{};
+    a.x = x; a.att = att; a.M = rows; a.wf = wf_in; a.b_in = b_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ab = ab; a.L = L;
+    if (fs) { a.fs = *fs; a.fs.on = 1; }
+    const int TM = 8192 / C, D = C / 4;
+    const size_t lds = (size_t)(C / 32) * TM * T_LDK * sizeof(float) + ((size_t)2 * TM * (2 * D + 8) + (size_t)D * (2 * TM + 8)) * sizeof(_Float16);
+    // (in-kernel FiLM coefficient rows sit in the q / k / v^T region, dead until the first head's tiles are written)
+    if (fs && (size_t)film_rows_cap(TM, L) * 2 * C * sizeof(float) > ((size_t)2 * TM * (2 * D + 8) + (size_t)D * (2 * TM + 8)) * sizeof(_Float16)) return hipErrorInvalidValue;
+    const void* kern = C == 128 ? reinterpret_cast<const void*>(sa_head_kernel<128>) : reinterpret_cast<const void*>(sa_head_kernel<256>);
+    if (hipError_t e = allow_full_lds(kern); e != hipSuccess) return e;
+    const int tiles = (rows + TM - 1) / TM;
+    if (C == 128) hipLaunchKernelGGL(sa_head_kernel<128>, dim3(tiles), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(sa_head_kernel<256>, dim3(tiles), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

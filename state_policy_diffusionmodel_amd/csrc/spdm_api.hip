@@ -1059,6 +1059,49 @@ struct Ctx {
             return out;
         }
         Tensor qkv = ralloc(rows, 3 * C);
+        // LayerNorm + in_proj + attention core in ONE kernel where the row tile holds whole samples (sa_head_kernel): q, k, v never
+        // reach memory.  (The workspace operations stay those of the three-launch path -- qkv is reserved and released unused -- so
+        // the slab sized by the dry run fits whichever path a call takes.)
+        // Only on large grids: a workgroup of the fused kernel is a 25-30 us chain (LayerNorm, twelve small products, four rounds of
+        // q/k/v tiles -> scores -> softmax -> P v with two to four barriers each) at two workgroups per CU, so it needs many rounds
+        // of workgroups to beat three launches that each fill the chip.  Measured (traced, same box; q/k/v + core launches -> fused):
+        // B = 4096: sa1 281 -> 234 us, sa2 171 -> 164, sa4 75 -> 70, sa3 50 -> 52; B = 512: 35 -> 38, 34 -> 44, 19 -> 32, 17 -> 34;
+        // B = 64: 13-17 -> 26-32 us each.  Rule: at least 2048 row tiles (SPDM_SA_HEAD=1 forces the fused kernel at any size: tests; SPDM_TUNE16: the threshold).
+        const int TMh = 8192 / C;
+        const bool head = h->split && sa_tail_supported(C, h->sw) && sa_head_supported(C, L, h->sw) && h->weights_loaded && w.qkv_wf &&
+                          (!fs || sa_tail_film_local(C, L)) && ((Bg() * L + TMh - 1) / TMh) >= ((h->sw & SW_SA_HEAD) ? 1 : spdm_tune(16, 2048));
+        if (head) {
+            free(xs);
+            Tensor att1 = ralloc(rows, C);
+            if (!err && !dry)
+                check(launch_sa_head(C, x.p, att1.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s, fs), "attention in_proj + core");
+            free(qkv);
+            if (h->split && sa_tail_supported(C, h->sw) && (!h->weights_loaded || w.tail_wf[0])) {
+                Tensor out = talloc(C, level);
+                if (!err && !dry)
+                    check(launch_sa_tail(C, att1.p, x.p, out.p, rows, w.tail_wf[0], w.tail_wf[1], w.tail_wf[2], w.out_proj.b, w.ff1.b,
+                                            w.ff2.b, w.ff_ln_g, w.ff_ln_b, abp, L, s, fs), "attention tail");
+                free(att1);
+                free(x);
+                if (ab) free(*ab);
+                return out;
+            }
+            // (no fused tail for this block: the GEMM chain below continues from att1)
+            Tensor av = talloc(C, level);
+            const int nt_av1 = gemm_geometry((rows / B) * Bg(), C, C, 1, 1, 1, (h->split && w.out_proj.ws) ? 1 : 0, h->sw).n_tiles;
+            StatsBuf avs = row_stats_alloc(rows, C, nt_av1);
+            linear(att1.p, C, rows, w.out_proj, av.p, EPI_BIAS_RESID, x.p, nullptr, nullptr, nullptr, avs.p);
+            free(att1);
+            free(x);
+            Tensor f1 = ralloc(rows, C);
+            linear(av.p, C, rows, w.ff1, f1.p, EPI_BIAS_GELU, nullptr, &avs, w.ff_ln_g, w.ff_ln_b);
+            free(avs);
+            Tensor out = talloc(C, level);
+            linear(f1.p, C, rows, w.ff2, out.p, EPI_BIAS_RESID, av.p);
+            free(f1);
+            free(av);
+            return out;
+        }
         if (h->split && sa_tail_supported(C, h->sw) && (!h->weights_loaded || w.qkv_wf)) {     // LayerNorm + in_proj in one 64-row kernel (sa_tail.hip)
             if (!err && !dry)
                 check(launch_sa_qkv(C, x.p, qkv.p, rows, w.qkv_wf, w.in_proj.b, w.ln_g, w.ln_b, abp, L, s, fs), "attention in_proj");

@@ -100,7 +100,7 @@ def test_unfused_fallbacks_match_fused_paths(monkeypatch):
     for env in ({}, {"SPDM_NO_SA_FUSED": "1"}, {"SPDM_NO_SA_FUSED": "1", "SPDM_ATTN_VALU": "1"}, {"SPDM_NO_W2": "1", "SPDM_NO_T512": "1"},
                 {"SPDM_NO_FILM_FOLD": "1"}, {"SPDM_NO_SA_TAIL": "1"}, {"SPDM_NO_WIDE": "1"}, {"SPDM_NO_FILM_LOCAL": "1"},
                 {"SPDM_NO_FUSED_SRC": "1"}, {"SPDM_NO_FUSED_SRC": "1", "SPDM_NO_FILM_LOCAL": "1", "SPDM_NO_SKINNY": "1"},
-                {"SPDM_FILM_LOCAL": "1"}, {"SPDM_NO_WP4": "1"}, {"SPDM_G2": "1"}, {"SPDM_NO_WP8": "1"}):
+                {"SPDM_FILM_LOCAL": "1"}, {"SPDM_NO_WP4": "1"}, {"SPDM_G2": "1"}, {"SPDM_NO_WP8": "1"}, {"SPDM_SA_HEAD": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = make_engine(32, 3, 1350, 2, sd, True)
@@ -524,5 +524,30 @@ def test_in_kernel_film_coefficients_match_the_coefficient_launch():
             got = eng.unet_forward(x, t, y).cpu()
             assert not eng.nonfinite()
             assert float((got - ref).abs().max()) <= 2e-6, (H, D, B)
+        finally:
+            eng.close()
+
+
+def test_fused_attention_head_kernel_matches_the_three_launch_path():
+    """sa_head_kernel (LayerNorm + in_proj + attention core in one kernel: q, k, v never reach memory) runs by itself only on
+    large grids (>= 2048 row tiles: measured).  Forced on (SPDM_SA_HEAD=1) at sizes the oracle checks in seconds -- every tile
+    geometry it supports (64 / 16 tokens at C = 128; 16 / 4 at C = 256; 32 / 8 at horizon 64), ragged batches, per-sample t --
+    it must match the oracle and the default path."""
+    cd = 33
+    sd = weights(cd, 21)
+    for H, D, B in ((32, 3, 37), (64, 6, 5), (16, 3, 9)):
+        g = torch.Generator().manual_seed(H * 7 + B)
+        x = torch.randn(B, 1, H, D, generator=g)
+        y = torch.randn(B, 1, 3, 11, generator=g)
+        t = (torch.arange(B) * 29) % 1000
+        want = unet_film_forward(sd, x, t, y).numpy()
+        eng = make_engine(H, D, cd, B, sd)
+        try:
+            ref = eng.unet_forward(x.cuda(), t, y.cuda()).cpu().numpy()
+            eng.set_switch("SPDM_SA_HEAD", True)
+            got = eng.unet_forward(x.cuda(), t, y.cuda()).cpu().numpy()
+            assert not eng.nonfinite()
+            assert np.abs(got - want).max() <= TOL, (H, D, B)
+            assert np.abs(got - ref).max() <= 5e-6, (H, D, B)
         finally:
             eng.close()
