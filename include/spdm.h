@@ -225,8 +225,9 @@ int  spdm_encoder_forward(spdm_encoder* e, int32_t n_images, const float* d_imag
 void spdm_encoder_destroy(spdm_encoder* e);
 
 /* Host-only test hook (no GPU call): the launch geometry chosen for a split-precision 3x3 / 3x1 convolution with the
- * statistics epilogue -- out = {m_tile, n_tile, n_tiles, slots, ksplit, skinny, st_m_tile, st_n_tiles, reserved_slots,
- * combine_rows}.  `switches` = 0 for the defaults. */
+ * statistics epilogue -- out = {m_tile, n_tile, n_tiles, slots, ksplit, kernel, st_m_tile, st_n_tiles, reserved_slots,
+ * combine_rows}; kernel: bit 0 = the small-grid kernel (conv_skinny.hip), bit 1 = the register-resident kernel (conv_reg.hip).
+ * `switches` = 0 for the defaults. */
 int  spdm_debug_geometry(int32_t M, int32_t N, int32_t K, int32_t HW, int32_t W, int32_t taps, uint32_t switches,
                          int32_t out[10]);
 

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("SPDM_BUILD_OUT") or os.path.join(HERE, "libspdm_hip.so")      # (SPDM_BUILD_OUT: a second build for A/B timing)
 OBJ = os.path.join(HERE, "csrc", "_obj" + ("_" + os.path.basename(LIB).replace(".", "_") if os.environ.get("SPDM_BUILD_OUT") else ""))
-SOURCES = ["conv_gemm.hip", "conv_wide.hip", "conv_skinny.hip", "elementwise.hip", "attention.hip", "sa_fused.hip", "sa_tail.hip", "encoder.hip", "spdm_api.hip"]
+SOURCES = ["conv_gemm.hip", "conv_wide.hip", "conv_skinny.hip", "conv_reg.hip", "elementwise.hip", "attention.hip", "sa_fused.hip", "sa_tail.hip", "encoder.hip", "spdm_api.hip"]
 HEADERS = ["kernels.h", "device_utils.h", os.path.join("..", "..", "include", "spdm.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("SPDM_DIAG") == "1":      # diagnostic build: in-kernel s_memtime stamps + experimental schedules

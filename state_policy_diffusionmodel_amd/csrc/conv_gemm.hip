@@ -752,6 +752,14 @@ int spdm_tune(int idx, int dflt) {
 GemmGeom gemm_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, bool stats_epi) {
     GemmGeom g;
     g.skinny = 0;
+    g.reg = 0;
+    if (stats_epi && conv_reg_geometry(M, N, K, HW, W, taps, split, sw)) {
+        g.reg = 1;
+        g.m_tile = 64; g.n_tile = 64; g.n_tiles = 1; g.ksplit = 1;
+        g.st_m_tile = 64; g.st_n_tiles = 1;
+        g.slots = stats_slots(HW, 64, 1);
+        return g;
+    }
     if (stats_epi && taps != 1 && conv_skinny_geometry(M, N, K, HW, W, taps, split, sw, &g.m_tile, &g.n_tile)) {
         g.skinny = 1;
         g.ksplit = 1;
@@ -864,7 +872,7 @@ bool gemm_takes_two_sources(const GemmArgs& a0) {
     if (a0.skip == nullptr || !a0.split || a0.wgt_frag == nullptr || (a0.sw & SW_NO_FUSED_SRC) || a0.epi != EPI_STATS) return false;
     GemmArgs a = a0;
     const GemmGeom g = gemm_geometry(a.geom_M > 0 ? a.geom_M : a.M, a.N, a.K, a.HW, a.W, a.taps, a.split, a.sw, a.epi == EPI_STATS && a.partial != nullptr);
-    if (g.skinny || g.m_tile == 512) return false;
+    if (g.skinny || g.reg || g.m_tile == 512) return false;
     a.ksplit = g.ksplit;
     return conv_wide_supported(a, g);
 }
@@ -929,6 +937,7 @@ hipError_t launch_gemm(const GemmArgs& a0, hipStream_t s) {
     if (fused_src && !g.skinny) return hipErrorInvalidValue;                            // (the plan asks gemm_takes_fused_source first)
     if (!fused_src && a.skip != nullptr && !gemm_takes_two_sources(a)) return hipErrorInvalidValue;   // (... gemm_takes_two_sources)
     if (g.skinny) return launch_conv_skinny(a, g, s);
+    if (g.reg) return launch_conv_reg64(a, g, s);
     if (g.ksplit > 1) {
         if ((size_t)g.ksplit * a.M * a.N * sizeof(float) > SPLITK_WORKSPACE_BYTES || a.dst_ld != a.N) return hipErrorInvalidValue;
         a.ksplit = g.ksplit;

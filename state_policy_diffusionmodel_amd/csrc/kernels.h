@@ -57,7 +57,7 @@ enum : unsigned {
     SW_T3_BIG = 1u << 5, SW_NO_SMALL_TPI3 = 1u << 6, SW_WIDE_N64_2X2 = 1u << 7, SW_NO_SA_FUSED = 1u << 8,
     SW_NO_SA_TAIL = 1u << 9, SW_ATTN_VALU = 1u << 10, SW_SA_NO_WLDS = 1u << 11, SW_NO_FILM_FOLD = 1u << 12,
     SW_NO_GRAPH = 1u << 13, SW_NO_SPLITK = 1u << 14, SW_ARENA_TRACE = 1u << 15, SW_NO_WIDE_PIPE = 1u << 16, SW_NO_SKINNY = 1u << 17, SW_DEEP = 1u << 18,
-    SW_NO_FILM_LOCAL = 1u << 19, SW_NO_FUSED_SRC = 1u << 20, SW_FILM_LOCAL = 1u << 21, SW_PIN_GEOMETRY = 1u << 22, SW_NO_WP4 = 1u << 23, SW_G2 = 1u << 24, SW_NO_WP8 = 1u << 25, SW_NO_SA_HEAD = 1u << 26, SW_SA_HEAD = 1u << 27,
+    SW_NO_FILM_LOCAL = 1u << 19, SW_NO_FUSED_SRC = 1u << 20, SW_FILM_LOCAL = 1u << 21, SW_PIN_GEOMETRY = 1u << 22, SW_NO_WP4 = 1u << 23, SW_G2 = 1u << 24, SW_NO_WP8 = 1u << 25, SW_NO_SA_HEAD = 1u << 26, SW_SA_HEAD = 1u << 27, SW_NO_REG64 = 1u << 28,
 };
 struct SwitchName { const char* env; unsigned bit; };
 inline const SwitchName* switch_table(int* n) {
@@ -70,7 +70,7 @@ inline const SwitchName* switch_table(int* n) {
         {"SPDM_NO_FILM_LOCAL", SW_NO_FILM_LOCAL}, {"SPDM_NO_FUSED_SRC", SW_NO_FUSED_SRC},
         {"SPDM_FILM_LOCAL", SW_FILM_LOCAL}, {"SPDM_PIN_GEOMETRY", SW_PIN_GEOMETRY},
         {"SPDM_NO_WP4", SW_NO_WP4}, {"SPDM_G2", SW_G2}, {"SPDM_NO_WP8", SW_NO_WP8},
-        {"SPDM_NO_SA_HEAD", SW_NO_SA_HEAD}, {"SPDM_SA_HEAD", SW_SA_HEAD}};
+        {"SPDM_NO_SA_HEAD", SW_NO_SA_HEAD}, {"SPDM_SA_HEAD", SW_SA_HEAD}, {"SPDM_NO_REG64", SW_NO_REG64}};
     *n = (int)(sizeof(t) / sizeof(t[0]));
     return t;
 }
@@ -121,6 +121,7 @@ struct GemmGeom {
     int slots;                       // statistics slots per sample of whoever writes them
     int ksplit;                      // > 1: split-K launch + combine
     int skinny;                      // 1: conv_skinny.hip (a handful of rows: whole-K slab in LDS, the waves of a workgroup split K)
+    int reg;                         // 1: conv_reg.hip (64 -> 64 channels on the width-8 level: activations in registers, weights in LDS)
     int st_m_tile, st_n_tiles;       // StatsRef geometry of the statistics (the GEMM's own tiling, or the combine kernel's)
 };
 // K = input channels (per tap); ksplit is only ever > 1 for split-precision 3x3 / 3x1 convolutions with the statistics
@@ -139,6 +140,9 @@ __host__ __device__ inline int combine_rows(int HW, int N) {
 // conv_skinny.hip: 3x3 / 3x1 convolutions of <= 256 rows (batch 1-4).  conv_skinny_geometry is the shape rule (false: not here)
 bool conv_skinny_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw, int* m_tile, int* n_tile);
 hipError_t launch_conv_skinny(const GemmArgs& a, const GemmGeom& g, hipStream_t s);
+// conv_reg.hip: 3x3 convolutions 64 -> 64 on width-8 maps at large batch (64-row wave tiles; one statistics slot per wave tile)
+bool conv_reg_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw);
+hipError_t launch_conv_reg64(const GemmArgs& a, const GemmGeom& g, hipStream_t s);
 hipError_t launch_splitk_combine(const float* partial, int ksplit, float* dst, int M, int N, int HW, double* stats,
                                  hipStream_t s);
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);

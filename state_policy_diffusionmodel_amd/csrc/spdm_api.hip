@@ -1892,7 +1892,7 @@ extern "C" int spdm_debug_geometry(int32_t M, int32_t N, int32_t K, int32_t HW, 
                                    int32_t out[10]) {
     if (!out || M <= 0 || N <= 0 || K <= 0 || HW <= 0 || W <= 0 || M % HW != 0) return fail(SPDM_ERR_INVALID, "bad argument");
     const GemmGeom g = gemm_geometry(M, N, K, HW, W, taps, /*split=*/1, switches, /*stats_epi=*/true);
-    out[0] = g.m_tile; out[1] = g.n_tile; out[2] = g.n_tiles; out[3] = g.slots; out[4] = g.ksplit; out[5] = g.skinny;
+    out[0] = g.m_tile; out[1] = g.n_tile; out[2] = g.n_tiles; out[3] = g.slots; out[4] = g.ksplit; out[5] = g.skinny | (g.reg << 1);
     out[6] = g.st_m_tile; out[7] = g.st_n_tiles;
     out[8] = std::max(std::max(std::max(g.slots, stats_slots(HW, 128, std::max(1, N / 64))), stats_slots(HW, combine_rows(HW, N), 1)),
                       std::max(stats_slots(HW, 16, std::max(1, N / 16)), stats_slots(HW, std::max(HW / 4, 1), 1)));   // = Ctx::salloc's reservation

@@ -24,7 +24,10 @@ def geometry(lib, M, N, K, HW, W, taps, sw=0):
     out = (ctypes.c_int32 * 10)()
     rc = lib.spdm_debug_geometry(M, N, K, HW, W, taps, sw, ctypes.byref(out))
     assert rc == 0, rc
-    return dict(zip(FIELDS, out))
+    g = dict(zip(FIELDS, out))
+    g["reg"] = g["skinny"] >> 1           # out[5]: bit 0 = conv_skinny.hip, bit 1 = conv_reg.hip
+    g["skinny"] &= 1
+    return g
 
 
 def stats_slots(HW, m_tile, n_tiles):
@@ -69,6 +72,10 @@ def test_statistics_layout_matches_the_launch_for_every_layer_and_batch(lib, H, 
             assert g["n_tile"] in (16, 32, 64, 128), tag
             assert g["m_tile"] in (16, 32, 64, 128, 256, 512), tag
             assert g["ksplit"] >= 1, tag
+            # conv_reg.hip: 64 -> 64 channels on width-8 maps, from one round of 8 waves per CU up; one slot per 64-row wave tile
+            assert bool(g["reg"]) == (N == 64 and K == 64 and W == 8 and taps == 9 and HW % 64 == 0 and M // 64 >= 2048), tag
+            if g["reg"]:
+                assert (g["m_tile"], g["n_tile"], g["ksplit"], g["skinny"]) == (64, 64, 1, 0), tag
             # the statistics layout is the launch's own tiling, or the combine kernel's when (and only when) there is a combine pass
             if g["ksplit"] > 1:
                 assert not g["skinny"], tag
@@ -106,8 +113,8 @@ def test_reservation_does_not_depend_on_the_batch(lib):
 
 
 def test_switches_change_the_geometry_but_keep_the_invariants(lib):
-    NO_SPLITK, NO_SKINNY, NO_WIDE = 1 << 14, 1 << 17, 1 << 0
-    for sw in (NO_SPLITK, NO_SKINNY, NO_SPLITK | NO_SKINNY, NO_WIDE):
+    NO_SPLITK, NO_SKINNY, NO_WIDE, NO_REG64 = 1 << 14, 1 << 17, 1 << 0, 1 << 28
+    for sw in (NO_SPLITK, NO_SKINNY, NO_SPLITK | NO_SKINNY, NO_WIDE, NO_REG64):
         for HW, W, N, K, taps in unet_conv_shapes(64, 6):
             for B in (1, 8, 64, 256, 512, 1024, 4096):
                 g = geometry(lib, B * HW, N, K, HW, W, taps, sw)
@@ -115,6 +122,8 @@ def test_switches_change_the_geometry_but_keep_the_invariants(lib):
                     assert g["ksplit"] == 1
                 if sw & NO_SKINNY:
                     assert not g["skinny"]
+                if sw & NO_REG64:
+                    assert not g["reg"]
                 if g["ksplit"] > 1:
                     assert (g["st_m_tile"], g["st_n_tiles"]) == (g["combine_rows"], 1)
                 else:

@@ -83,6 +83,26 @@ def test_wide_conv_kernel_shapes_against_exact_fp32_path():
         assert 0.0 <= ms[2] <= 1e-5, ((B, H, W, Cin, Cout, taps, pro, epi), "GroupNorm totals", ms[2])
 
 
+def test_register_resident_conv_against_exact_fp32_path():
+    """conv_reg64_kernel (conv_reg.hip: 64 -> 64 channels on width-8 maps, activations in registers, weights in LDS; chosen from
+    2048 wave tiles of 64 rows up) against the exact fp32-MFMA kernel on the same synthetic data, outputs AND per-sample GroupNorm
+    totals: all three prologues, 1 / 2 / 3 / 4 / 8 wave tiles per sample (both halo rows outside the image, one, none), a grid
+    whose last workgroup is ragged, and more tiles than one round of waves."""
+    from state_policy_diffusionmodel_amd import _lib
+    lib = _lib.load()
+    geo = (ctypes.c_int32 * 10)()
+    cases = [  # B, H, W, Cin, Cout, taps, pro, epi
+        (512, 32, 8, 64, 64, 9, 2, 0), (600, 32, 8, 64, 64, 9, 1, 0), (513, 32, 8, 64, 64, 9, 0, 0), (300, 64, 8, 64, 64, 9, 2, 0),
+        (700, 24, 8, 64, 64, 9, 2, 0), (1100, 16, 8, 64, 64, 9, 1, 0), (2200, 8, 8, 64, 64, 9, 2, 0), (1031, 32, 8, 64, 64, 9, 2, 0),
+    ]
+    for B, H, W, Cin, Cout, taps, pro, epi in cases:
+        assert lib.spdm_debug_geometry(B * H * W, Cout, Cin, H * W, W, taps, 0, ctypes.byref(geo)) == 0 and geo[5] == 2, (B, H, list(geo))
+        ms = (ctypes.c_double * 3)()
+        _lib.check(lib.spdm_bench_gemm(0, B, H, W, Cin, Cout, taps, pro, epi, 1, 1, 0, ms), "spdm_bench_gemm")
+        assert 0.0 <= ms[1] <= 5e-5, ((B, H, W, Cin, Cout, taps, pro, epi), ms[1])
+        assert 0.0 <= ms[2] <= 1e-5, ((B, H, W, Cin, Cout, taps, pro, epi), "GroupNorm totals", ms[2])
+
+
 def test_split_k_launches_against_exact_fp32_path():
     """Small grids: split-K conv launches + the fixed-order combine kernel (outputs and GroupNorm totals) against the exact
     fp32 kernel -- batch 1..64 at every level, 3x3 and 3x1, width-2 maps on the 256-row zero-tap-skipping tiles, a sample

@@ -100,7 +100,7 @@ def test_unfused_fallbacks_match_fused_paths(monkeypatch):
     for env in ({}, {"SPDM_NO_SA_FUSED": "1"}, {"SPDM_NO_SA_FUSED": "1", "SPDM_ATTN_VALU": "1"}, {"SPDM_NO_W2": "1", "SPDM_NO_T512": "1"},
                 {"SPDM_NO_FILM_FOLD": "1"}, {"SPDM_NO_SA_TAIL": "1"}, {"SPDM_NO_WIDE": "1"}, {"SPDM_NO_FILM_LOCAL": "1"},
                 {"SPDM_NO_FUSED_SRC": "1"}, {"SPDM_NO_FUSED_SRC": "1", "SPDM_NO_FILM_LOCAL": "1", "SPDM_NO_SKINNY": "1"},
-                {"SPDM_FILM_LOCAL": "1"}, {"SPDM_NO_WP4": "1"}, {"SPDM_G2": "1"}, {"SPDM_NO_WP8": "1"}, {"SPDM_SA_HEAD": "1"}):
+                {"SPDM_FILM_LOCAL": "1"}, {"SPDM_NO_WP4": "1"}, {"SPDM_G2": "1"}, {"SPDM_NO_WP8": "1"}, {"SPDM_SA_HEAD": "1"}, {"SPDM_NO_REG64": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = make_engine(32, 3, 1350, 2, sd, True)
