@@ -1,6 +1,6 @@
-// conv_reg.hip -- 3x3 convolution 64 -> 64 channels on the width-8 level (inc's second conv and the last conv of up3,
-// models/Unet_FiLmLayer.py:101-115, 256, 266) with the ACTIVATIONS IN REGISTERS and the WEIGHTS IN LDS -- the opposite
-// placement of conv_wide.hip.
+// conv_reg.hip -- 3x3 convolution 64 -> 64 channels on the width-8 and width-4 levels (inc's second conv, the last conv of up3,
+// down1's first DoubleConvolution and the last conv of up2: models/Unet_FiLmLayer.py:101-115, 256-266) with the ACTIVATIONS IN
+// REGISTERS and the WEIGHTS IN LDS -- the opposite placement of conv_wide.hip.
 //
 // Why: a 64-wide layer gives a wave a 64 x 64 accumulator strip, so each 16 KB of weight fragments is good for 96 MFMAs only
 // and every wave streams the layer's whole 144 KB per 64 rows -- two thirds of a CU's L2 bandwidth at full MFMA rate -- while the
@@ -9,14 +9,18 @@
 // ones.  Here
 //   * the whole layer's split-fp16 weights (9 taps x 64 x 64 x {hi, lo} = 144 KB) are staged in LDS ONCE per workgroup, which is
 //     persistent (one per CU, 8 waves); B operands are conflict-free ds_read_b128 of 1-KiB lane-contiguous blocks;
-//   * a wave owns 64 output positions = 8 image rows x 8 columns of one sample and loads them (+ one image row above and
-//     below) straight from global memory in MFMA A-operand layout: lane (kg, l16) = position l16 of a row tile, channels
-//     8 kg .. 8 kg + 7 of the 32-channel k-step; the GroupNorm -> GELU prologue and the hi / lo split run on registers;
-//   * row tile t holds image rows (h0 + t, h0 + t + 4) in its two 8-lane halves, so the VERTICAL neighbours of a tile are
-//     another tile's registers (t - 1 / t + 1), except at the block edge, where one composite tile is put together from the
-//     halo row and half a tile with two DPP moves per register; the HORIZONTAL neighbours are a one-lane DPP row shift with
-//     the edge column masked.  No activation ever touches LDS, the waves never meet after the weight staging (no barrier, no
-//     hand-over), and the load latency of one wave hides under the MFMAs of the other wave of its SIMD;
+//   * a wave owns 64 output positions = 8 image rows x 8 columns (16 x 4 on the width-4 level) of one sample and loads them (+ one
+//     image row above and below) straight from global memory in MFMA A-operand layout: lane (kg, l16) = position l16 of a row
+//     tile, channels 8 kg .. 8 kg + 7 of the 32-channel k-step; the GroupNorm -> GELU prologue and the hi / lo split run on registers;
+//   * row tile t holds image rows h0 + t, h0 + t + 4 (, + 8, + 12) interleaved lane by lane, so the VERTICAL neighbours of a tile
+//     are another tile's registers (t - 1 / t + 1), except at the block edge, where one composite tile is put together from the
+//     halo row and a tile shifted by one lane; the HORIZONTAL neighbours are ONE DPP row shift per register whose zero fill at the
+//     end of the 16-lane row is exactly the image edge.  No activation ever touches LDS, the waves never meet after the weight
+//     staging (no barrier, no hand-over); the next tile's rows are requested before this tile's stores (vmcnt is in order);
+//   * the A operand of unit (tap, row tile) u + 1 is put together in the shadow of unit u's 12 MFMAs -- but VALU work and the matrix
+//     pipe of a SIMD overlap only partly on this chip (tools/probes/coexec_probe.hip: another wave's plain VALU stream hides 65 %
+//     under MFMAs, v_pk_* FP32 not at all), so the launch is close to MFMA time + prologue time: 241-254 us for 110 us of MFMAs
+//     at B = 4096 against 333-350 us on conv_wide's 256 x 64 variant;
 //   * output channels are permuted among the B tiles (tile nb' holds channels 4 l16 + nb') so that a lane ends up with four
 //     consecutive channels of a position: 16-byte stores straight from the accumulators, whole 256-byte rows per instruction.
 // Same math and contracts as the other convolution kernels: split-fp16 operands (activations x16, weights x128), hi*hi + hi*lo +
@@ -52,32 +56,32 @@ __device__ __forceinline__ void r_split2(float a, float b, int& h, int& l) {
     l = __builtin_bit_cast(int, ll);
 }
 
-// Lane map of a row tile: lane l16 of a 16-lane DPP row = column w = l16 >> 1 of image row A (even lanes) or B (odd lanes).
-// horizontal neighbour: lane i <- lane i + 2 DX of its DPP row; bound_ctrl writes zero where the source falls off the row, which
-// is exactly the image edge (w = 7 for DX = +1, w = 0 for DX = -1): one instruction per register, no mask
-template <int DX>
+// Lane map of a row tile (RPT = 16 / W image rows per tile): lane l16 of a 16-lane DPP row = column w = l16 / RPT of image row
+// h0 + t + 4 (l16 % RPT).  Horizontal neighbour: lane i <- lane i + RPT DX of its DPP row; bound_ctrl writes zero where the source
+// falls off the row, which is exactly the image edge (w = W - 1 for DX = +1, w = 0 for DX = -1): one instruction per register, no mask
+template <int DX, int RPT>
 __device__ __forceinline__ RTile r_shift(const RTile& t) {
     if constexpr (DX == 0) return t;
     RTile c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        c.h[r] = __builtin_amdgcn_update_dpp(0, t.h[r], DX > 0 ? 0x102 : 0x112, 0xf, 0xf, true);     // row_shl:2 / row_shr:2
-        c.l[r] = __builtin_amdgcn_update_dpp(0, t.l[r], DX > 0 ? 0x102 : 0x112, 0xf, 0xf, true);
+        c.h[r] = __builtin_amdgcn_update_dpp(0, t.h[r], (DX > 0 ? 0x100 : 0x110) + RPT, 0xf, 0xf, true);     // row_shl:RPT / row_shr:RPT
+        c.l[r] = __builtin_amdgcn_update_dpp(0, t.l[r], (DX > 0 ? 0x100 : 0x110) + RPT, 0xf, 0xf, true);
     }
     return c;
 }
-// composite tile at the block edge: the lanes of one parity keep `halo`, the others take the neighbouring lane of `t`
-//   UP  : rows (h0 - 1 | h0 + 3): odd lanes  <- the even lanes of tile 3 (lane i - 1)
-//   DOWN: rows (h0 + 4 | h0 + 8): even lanes <- the odd lanes of tile 0  (lane i + 1)
+// composite tile at the block edge: the lanes of one image-row slot keep `halo`, the others take the neighbouring lane of `t`
+//   UP  : rows (h0 - 1 | h0 + 3 | ..): slot 0 keeps the halo row, slot s >= 1 <- slot s - 1 of tile 3 (lane i - 1)
+//   DOWN: rows (h0 + 4 | .. | h0 + 4 RPT): the last slot keeps the halo row, slot s <- slot s + 1 of tile 0 (lane i + 1)
 template <bool UP>
-__device__ __forceinline__ RTile r_composite(const RTile& halo, const RTile& t, bool odd) {
+__device__ __forceinline__ RTile r_composite(const RTile& halo, const RTile& t, bool keep_halo) {
     RTile c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int mh = __builtin_amdgcn_update_dpp(0, t.h[r], UP ? 0x111 : 0x101, 0xf, 0xf, true);     // row_shr:1 / row_shl:1
         const int ml = __builtin_amdgcn_update_dpp(0, t.l[r], UP ? 0x111 : 0x101, 0xf, 0xf, true);
-        c.h[r] = (odd == UP) ? mh : halo.h[r];
-        c.l[r] = (odd == UP) ? ml : halo.l[r];
+        c.h[r] = keep_halo ? halo.h[r] : mh;
+        c.l[r] = keep_halo ? halo.l[r] : ml;
     }
     return c;
 }
@@ -93,7 +97,7 @@ __device__ unsigned long long g_reg_stamps[2 * 3 * 8];
 #define REG_STAMP(k_)
 #endif
 
-template <int PRO>
+template <int PRO, int WD>
 __global__ __launch_bounds__(R_NTHR, 1) void conv_reg64_kernel(const GemmArgs a, const int epi_slots, const int nw, const int n_wt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char r_smem[];
     r_i32x4* const Wl = reinterpret_cast<r_i32x4*>(r_smem);
@@ -104,16 +108,52 @@ __global__ __launch_bounds__(R_NTHR, 1) void conv_reg64_kernel(const GemmArgs a,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, kg = lane >> 4;
 
+    const int HW = a.HW, H = a.H;
+    constexpr int RPT = 16 / WD, TH = 4 * RPT;      // image rows per row tile / per wave tile (W = 8: 2, 8; W = 4: 4, 16)
+    const int wcol = l16 / RPT, hsel = l16 % RPT;   // lane map of a row tile: column, image-row slot
+
+    // raw rows of wave tile wt_: tiles 0..3 = image rows (h0 + t | h0 + t + 4 | ..), tile 4 = halo rows (h0 - 1 in slot 0, h0 + TH in
+    // the last slot; the slots between, W = 4 only, are never used)
+#ifdef REG_ABL_NOLOAD
+#define R_ROWPTR(sb_, hrow_) (a.src + lane * 4 + (size_t)((hrow_) & 1) * 256)       /* (the same few lines for every tile: cache hits) */
+#else
+#define R_ROWPTR(sb_, hrow_) ((sb_) + (size_t)((hrow_) * WD + wcol) * a.src_ld)
+#endif
+#define R_LOAD_RAW(wt_, ks_)                                                                            \
+    {                                                                                                  \
+        const int m0_ = (wt_) * 64;                                                                    \
+        const int b_ = m0_ / HW;                                                                       \
+        const int h0_ = (m0_ - b_ * HW) / WD;                                                          \
+        const float* sb_ = a.src + (size_t)b_ * HW * a.src_ld + kg * 8;                                \
+        const int hh_ = hsel ? h0_ + TH : h0_ - 1;                                                     \
+        _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) {                                             \
+            const int hrow_ = (t_ < 4) ? h0_ + t_ + 4 * hsel : min(max(hh_, 0), H - 1);                \
+            const float* p_ = R_ROWPTR(sb_, hrow_);                                                    \
+            raw[ks_][t_][0] = *reinterpret_cast<const r_f32x4*>(p_ + 32 * (ks_));                      \
+            raw[ks_][t_][1] = *reinterpret_cast<const r_f32x4*>(p_ + 32 * (ks_) + 4);                  \
+        }                                                                                              \
+    }
+    r_f32x4 raw[2][5][2];
+    const int wt_first = (int)blockIdx.x * nw + wave, wt_step = (int)gridDim.x * nw;
+    R_LOAD_RAW(min(wt_first, n_wt - 1), 0)          // (the first tile's rows fly under the weight staging)
+
     // ---- weights -> LDS, once: block ((tap 2 + ks) 4 + nb') x {hi, lo}, lane (kg, l16) <- row n = 4 l16 + nb' of the fragment-order
     //      copy (frag_order_weights, kernels.h: block ((tap 2 + ks) 4 + n / 16) x {hi, lo}, lane (kg, n % 16)) ----
     {
+        // (all 18 loads of a thread in flight before the first LDS write: the weights are cold in L2 inside a real step, and a
+        //  load -> store loop is 18 dependent round trips -- measured +5 us per launch against the warm micro-benchmark)
         const r_i32x4* wsrc = reinterpret_cast<const r_i32x4*>(a.wgt_frag);
-        for (int i = tid; i < R_WBYTES / 16; i += R_NTHR) {
+        r_i32x4 wreg[R_WBYTES / 16 / R_NTHR];
+#pragma unroll
+        for (int j = 0; j < R_WBYTES / 16 / R_NTHR; ++j) {
+            const int i = tid + j * R_NTHR;
             const int ln = i & 63, blk = i >> 6;
             const int part = blk & 1, nbp = (blk >> 1) & 3, tk = blk >> 3;
             const int n = 4 * (ln & 15) + nbp;
-            Wl[i] = wsrc[(((tk * 4 + (n >> 4)) * 2 + part) << 6) + (ln & 48) + (n & 15)];
+            wreg[j] = wsrc[(((tk * 4 + (n >> 4)) * 2 + part) << 6) + (ln & 48) + (n & 15)];
         }
+#pragma unroll
+        for (int j = 0; j < R_WBYTES / 16 / R_NTHR; ++j) Wl[tid + j * R_NTHR] = wreg[j];
         if (pro && tid < 128) gb[tid] = (tid < 64) ? a.pro_gamma[tid] : a.pro_beta[tid - 64];
         // mean / rstd of the sample of every tile this wave will walk: lane i takes the wave's i-th tile, so the whole table is ONE
         // dependent round trip, under the weight staging, instead of one per tile in front of its prologue
@@ -130,35 +170,9 @@ __global__ __launch_bounds__(R_NTHR, 1) void conv_reg64_kernel(const GemmArgs a,
     }
     __syncthreads();
     if (wave >= nw) return;                 // (no barrier below: the waves are independent from here on)
-    const int HW = a.HW, H = a.H;
-    const int wcol = l16 >> 1, half = l16 & 1;      // lane map of a row tile: column, image row A / B
-
 #ifdef SPDM_DIAG_REG
     int tile_no = -1;
 #endif
-    // raw rows of wave tile wt_: tiles 0..3 = image rows (h0 + t | h0 + t + 4), tile 4 = halo rows (h0 - 1 | h0 + 8)
-#ifdef REG_ABL_NOLOAD
-#define R_ROWPTR(sb_, hrow_) (a.src + lane * 4 + (size_t)((hrow_) & 1) * 256)       /* (the same few lines for every tile: cache hits) */
-#else
-#define R_ROWPTR(sb_, hrow_) ((sb_) + (size_t)((hrow_) * 8 + wcol) * a.src_ld)
-#endif
-#define R_LOAD_RAW(wt_, ks_)                                                                            \
-    {                                                                                                  \
-        const int m0_ = (wt_) * 64;                                                                    \
-        const int b_ = m0_ / HW;                                                                       \
-        const int h0_ = (m0_ - b_ * HW) >> 3;                                                          \
-        const float* sb_ = a.src + (size_t)b_ * HW * a.src_ld + kg * 8;                                \
-        const int hh_ = half ? h0_ + 8 : h0_ - 1;                                                      \
-        _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) {                                             \
-            const int hrow_ = (t_ < 4) ? h0_ + t_ + 4 * half : min(max(hh_, 0), H - 1);                \
-            const float* p_ = R_ROWPTR(sb_, hrow_);                                                    \
-            raw[ks_][t_][0] = *reinterpret_cast<const r_f32x4*>(p_ + 32 * (ks_));                      \
-            raw[ks_][t_][1] = *reinterpret_cast<const r_f32x4*>(p_ + 32 * (ks_) + 4);                  \
-        }                                                                                              \
-    }
-    r_f32x4 raw[2][5][2];
-    const int wt_first = (int)blockIdx.x * nw + wave, wt_step = (int)gridDim.x * nw;
-    R_LOAD_RAW(min(wt_first, n_wt - 1), 0)
     int tile_i = 0;
     for (int wt = wt_first; wt < n_wt; wt += wt_step, ++tile_i) {
 #ifdef SPDM_DIAG_REG
@@ -168,8 +182,8 @@ __global__ __launch_bounds__(R_NTHR, 1) void conv_reg64_kernel(const GemmArgs a,
         R_LOAD_RAW(wt, 1)            // (k-step 1's half of the rows: behind the previous tile's stores in vmcnt order, not needed before the first MFMA phase is over)
         const int m0 = wt * 64;
         const int b = m0 / HW;
-        const int h0 = (m0 - b * HW) >> 3;
-        const int hh = half ? h0 + 8 : h0 - 1;
+        const int h0 = (m0 - b * HW) / WD;
+        const int hh = hsel ? h0 + TH : h0 - 1;
         const bool halo_ok = hh >= 0 && hh < H;
         REG_STAMP(1)
         float mean = 0.f, rstd = 1.f;
@@ -225,8 +239,8 @@ __global__ __launch_bounds__(R_NTHR, 1) void conv_reg64_kernel(const GemmArgs a,
                 }
             }
             if (ks == 0) { REG_STAMP(3) } else { REG_STAMP(5) }
-            T[5] = r_composite<false>(T[4], T[0], half != 0);      // even lanes <- image row h0 + 4 (odd lanes of tile 0); odd lanes keep h0 + 8
-            T[4] = r_composite<true>(T[4], T[3], half != 0);       // odd lanes <- image row h0 + 3 (even lanes of tile 3); even lanes keep h0 - 1
+            T[5] = r_composite<false>(T[4], T[0], hsel == RPT - 1);      // slot s <- image row h0 + 4 (s + 1) (slot s + 1 of tile 0); the last keeps h0 + TH
+            T[4] = r_composite<true>(T[4], T[3], hsel == 0);             // slot s <- image row h0 + 4 s - 1 (slot s - 1 of tile 3); slot 0 keeps h0 - 1
 
             // ---- 36 units (tap, row tile) x 4 B tiles x 3 MFMAs.  The A operand of unit u + 1 is put together (8 DPP moves, or
             //      nothing when dx = 0) in the shadow of unit u's 12 MFMAs; the B tiles of tap + 1 replace those of tap pair by pair
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(R_NTHR, 1) void conv_reg64_kernel(const GemmArgs a,
             {                                                                                                  \
                 const int src_ = R_SRC(u_), dx_ = ((u_) >> 2) % 3 - 1;                                         \
                 const RTile& base_ = (src_ < 0) ? T[4] : (src_ > 3) ? T[5] : T[src_ < 0 ? 0 : src_ > 3 ? 3 : src_]; \
-                dst_ = (dx_ == 0 || REG_NOSHIFT) ? base_ : (dx_ > 0) ? r_shift<1>(base_) : r_shift<-1>(base_);  \
+                dst_ = (dx_ == 0 || REG_NOSHIFT) ? base_ : (dx_ > 0) ? r_shift<1, RPT>(base_) : r_shift<-1, RPT>(base_);  \
             }
 #define R_LOAD_B(p_, tap_)                                                                                     \
             {                                                                                                  \
@@ -312,12 +326,12 @@ __global__ __launch_bounds__(R_NTHR, 1) void conv_reg64_kernel(const GemmArgs a,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * kg + j;
-                const int hrow = h0 + t + 4 * (r & 1);
+                const int hrow = h0 + t + 4 * (r % RPT);
                 const r_f32x4 v = {acc[t][0][j] * R_DESCALE, acc[t][1][j] * R_DESCALE, acc[t][2][j] * R_DESCALE, acc[t][3][j] * R_DESCALE};
 #ifdef REG_ABL_NOSTORE
                 if (v.x == 1234.5f)
 #endif
-                *reinterpret_cast<r_f32x4*>(dbase + (size_t)(hrow * 8 + (r >> 1)) * a.dst_ld) = v;
+                *reinterpret_cast<r_f32x4*>(dbase + (size_t)(hrow * WD + r / RPT) * a.dst_ld) = v;
                 s1 += (v.x + v.y) + (v.z + v.w);
                 s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
@@ -342,13 +356,15 @@ extern "C" int spdm_debug_reg_stamps(unsigned long long* out48) {
 
 // shape rule (gemm_geometry asks before the plan is made; M = the rows the geometry is chosen for)
 bool conv_reg_geometry(int M, int N, int K, int HW, int W, int taps, int split, unsigned sw) {
-    if (!split || taps != 9 || N != 64 || K != 64 || W != 8 || HW % 64 != 0 || (sw & SW_NO_REG64)) return false;
-    return M / 64 >= spdm_tune(17, 2048);           // wave tiles: one round of 8 waves on every CU
+    if (!split || taps != 9 || N != 64 || K != 64 || !(W == 8 || W == 4) || HW % 64 != 0 || (sw & SW_NO_REG64)) return false;
+    // from one wave tile per CU up (tools/bench_convs.py, old / new us per launch: 256 tiles 20 / 16.6 on both levels, 128 tiles 10 / 15.8
+    // -- a launch costs ~15 us whatever its size: 144 KB of weights into LDS per workgroup, then at least one whole tile per wave)
+    return M / 64 >= spdm_tune(17, 256);
 }
 
 hipError_t launch_conv_reg64(const GemmArgs& a, const GemmGeom& g, hipStream_t s) {
     // shape contract of the kernel -- checked on the host so that a bad plan can never fault the GPU
-    if (!a.split || a.wgt_frag == nullptr || a.taps != 9 || a.N != 64 || a.K != 64 || a.W != 8 || a.H < 8 || a.HW != a.H * 8 ||
+    if (!a.split || a.wgt_frag == nullptr || a.taps != 9 || a.N != 64 || a.K != 64 || !(a.W == 8 || a.W == 4) || a.H < 64 / a.W || a.HW != a.H * a.W ||
         a.HW % 64 != 0 || a.M <= 0 || a.M % a.HW != 0 || a.src_ld % 4 != 0 || a.src_ld < 64 || a.dst_ld % 4 != 0 || a.dst_ld < 64 ||
         a.epi != EPI_STATS || a.epi_stats == nullptr || a.row_stats != nullptr || a.skip != nullptr || a.ksplit > 1 || a.debug != 0 ||
         a.pro < PRO_NONE || a.pro > PRO_GN_GELU || g.m_tile != 64 || g.n_tile != 64 || g.n_tiles != 1)
@@ -365,9 +381,14 @@ hipError_t launch_conv_reg64(const GemmArgs& a, const GemmGeom& g, hipStream_t s
         hipLaunchKernelGGL(kern, dim3(grid), dim3(R_NTHR), lds, s, a, g.slots, nw, n_wt);
         return hipGetLastError();
     };
-    if (a.pro == PRO_NONE) return launch(conv_reg64_kernel<PRO_NONE>);
-    if (a.pro == PRO_GN) return launch(conv_reg64_kernel<PRO_GN>);
-    return launch(conv_reg64_kernel<PRO_GN_GELU>);
+    if (a.W == 8) {
+        if (a.pro == PRO_NONE) return launch(conv_reg64_kernel<PRO_NONE, 8>);
+        if (a.pro == PRO_GN) return launch(conv_reg64_kernel<PRO_GN, 8>);
+        return launch(conv_reg64_kernel<PRO_GN_GELU, 8>);
+    }
+    if (a.pro == PRO_NONE) return launch(conv_reg64_kernel<PRO_NONE, 4>);
+    if (a.pro == PRO_GN) return launch(conv_reg64_kernel<PRO_GN, 4>);
+    return launch(conv_reg64_kernel<PRO_GN_GELU, 4>);
 }
 
 }  // namespace spdm

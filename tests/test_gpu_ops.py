@@ -84,16 +84,20 @@ def test_wide_conv_kernel_shapes_against_exact_fp32_path():
 
 
 def test_register_resident_conv_against_exact_fp32_path():
-    """conv_reg64_kernel (conv_reg.hip: 64 -> 64 channels on width-8 maps, activations in registers, weights in LDS; chosen from
-    2048 wave tiles of 64 rows up) against the exact fp32-MFMA kernel on the same synthetic data, outputs AND per-sample GroupNorm
-    totals: all three prologues, 1 / 2 / 3 / 4 / 8 wave tiles per sample (both halo rows outside the image, one, none), a grid
-    whose last workgroup is ragged, and more tiles than one round of waves."""
+    """conv_reg64_kernel (conv_reg.hip: 64 -> 64 channels on width-8 and width-4 maps, activations in registers, weights in LDS;
+    chosen from 256 wave tiles of 64 rows up) against the exact fp32-MFMA kernel on the same synthetic data, outputs AND
+    per-sample GroupNorm totals: all three prologues, 1 / 2 / 3 / 4 / 8 wave tiles per sample (both halo rows outside the image,
+    one, none), grids of one wave per workgroup / a ragged last workgroup / several tiles per wave."""
     from state_policy_diffusionmodel_amd import _lib
     lib = _lib.load()
     geo = (ctypes.c_int32 * 10)()
     cases = [  # B, H, W, Cin, Cout, taps, pro, epi
         (512, 32, 8, 64, 64, 9, 2, 0), (600, 32, 8, 64, 64, 9, 1, 0), (513, 32, 8, 64, 64, 9, 0, 0), (300, 64, 8, 64, 64, 9, 2, 0),
         (700, 24, 8, 64, 64, 9, 2, 0), (1100, 16, 8, 64, 64, 9, 1, 0), (2200, 8, 8, 64, 64, 9, 2, 0), (1031, 32, 8, 64, 64, 9, 2, 0),
+        # width-4 maps (level 1): 16 image rows per wave tile -- the whole map at horizon 32, 2 / 3 tiles per sample beyond
+        (2048, 16, 4, 64, 64, 9, 0, 0), (2100, 16, 4, 64, 64, 9, 2, 0), (1100, 32, 4, 64, 64, 9, 2, 0), (700, 48, 4, 64, 64, 9, 1, 0),
+        # small grids: one wave per workgroup (256 tiles), two with a ragged last workgroup, three
+        (64, 32, 8, 64, 64, 9, 2, 0), (100, 32, 8, 64, 64, 9, 1, 0), (257, 16, 4, 64, 64, 9, 2, 0), (131, 32, 8, 64, 64, 9, 0, 0),
     ]
     for B, H, W, Cin, Cout, taps, pro, epi in cases:
         assert lib.spdm_debug_geometry(B * H * W, Cout, Cin, H * W, W, taps, 0, ctypes.byref(geo)) == 0 and geo[5] == 2, (B, H, list(geo))
