@@ -1,10 +1,10 @@
-# same-box A/B of one kernel-selection switch over a few batches (graph-replay step time), alternating: usage ab_switch.sh <out> <SWITCH> "<batches>"
+# same-box A/B of one kernel-selection switch over a few batches (graph-replay step time), alternating: usage ab_switch.sh <out> <SWITCH=1 | assignment> "<batches>"
 set -e
 out=gpurun_out/${1:-absw}; mkdir -p $out
 for rep in 1 2 3; do
   for B in $3; do
     timeout -k 10 120 python bench.py --batch $B --steps 40 --warmup 5 --no-cpu-baseline > $out/base_b${B}_$rep.json 2>/dev/null
-    env $2=1 timeout -k 10 120 python bench.py --batch $B --steps 40 --warmup 5 --no-cpu-baseline > $out/sw_b${B}_$rep.json 2>/dev/null
+    env $2 timeout -k 10 120 python bench.py --batch $B --steps 40 --warmup 5 --no-cpu-baseline > $out/sw_b${B}_$rep.json 2>/dev/null
   done
 done
 python3 - "$out" "$3" <<'PY'
