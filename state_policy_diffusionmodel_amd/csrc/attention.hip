@@ -246,6 +246,21 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
+typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+// hi / lo fragments of 8 values f(0..7): four split_pair_f16 (device_utils.h: 4 instructions per pair)
+template <typename F>
+__device__ __forceinline__ void split8(f16x8a& h, f16x8a& l, F f) {
+    u32x4a hu, lu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned a, b;
+        split_pair_f16(f(2 * q), f(2 * q + 1), a, b);
+        hu[q] = a;
+        lu[q] = b;
+    }
+    h = __builtin_bit_cast(f16x8a, hu);
+    l = __builtin_bit_cast(f16x8a, lu);
+}
 // exp(x) for x <= 0 through v_exp_f32 with a compensated argument (keeps ~1e-7 relative error up to |x| ~ 80)
 __device__ __forceinline__ float exp_neg(float x) {
     const float t = x * 1.44269504f;
@@ -320,14 +335,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     for (int ks = 0; ks < KS; ++ks) {
         const float* qp = base + (size_t)qc * ld + 16 * ks + 8 * kh;
         const f32x4a a0 = *reinterpret_cast<const f32x4a*>(qp), a1 = *reinterpret_cast<const f32x4a*>(qp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 h, l2;
-            split1((a0[e] * scale) * 16.0f, h, l2);
-            qh[ks][e] = h; ql[ks][e] = l2;
-            split1((a1[e] * scale) * 16.0f, h, l2);
-            qh[ks][4 + e] = h; ql[ks][4 + e] = l2;
-        }
+        split8(qh[ks], ql[ks], [&](int e) { return ((e < 4 ? a0[e & 3] : a1[e & 3]) * scale) * 16.0f; });
     }
 
     f32x16a acc_o[MO];
@@ -380,14 +388,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         // P^T fragments straight from the registers (k-step s = registers 8s .. 8s+7)
         f16x8a p_h[2], p_l[2];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 h, l2;
-                split1(sc[8 * s2 + j], h, l2);
-                p_h[s2][j] = h;
-                p_l[s2][j] = l2;
-            }
+        for (int s2 = 0; s2 < 2; ++s2) split8(p_h[s2], p_l[s2], [&](int j) { return sc[8 * s2 + j]; });
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) {
 #pragma unroll

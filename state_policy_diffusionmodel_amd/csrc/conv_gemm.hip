@@ -63,10 +63,8 @@ constexpr float SPLIT_DESCALE = 1.0f / 2048.0f;
 // elements 2,3 are replaced by 0,1.)
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 split_pair(float a, float b) {
-    const float xa = a * SPLIT_ACT_SCALE, xb = b * SPLIT_ACT_SCALE;
-    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
-    const f16x2 h = {ha, hb};
-    const f16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    unsigned h, l;
+    split_pair_f16(a * SPLIT_ACT_SCALE, b * SPLIT_ACT_SCALE, h, l);
     return f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 

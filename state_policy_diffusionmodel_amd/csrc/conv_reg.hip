@@ -48,12 +48,10 @@ constexpr int R_MAXT = 192;                          // tiles one wave may walk 
 struct RTile { r_i32x4 h, l; };                       // one A operand pair: 8 fp16 hi | 8 fp16 lo of this lane's position
 
 __device__ __forceinline__ void r_split2(float a, float b, int& h, int& l) {
-    const float xa = a * R_ACT_SCALE, xb = b * R_ACT_SCALE;
-    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
-    const r_f16x2 hh = {ha, hb};
-    const r_f16x2 ll = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
-    h = __builtin_bit_cast(int, hh);
-    l = __builtin_bit_cast(int, ll);
+    unsigned hu, lu;
+    split_pair_f16(a * R_ACT_SCALE, b * R_ACT_SCALE, hu, lu);
+    h = (int)hu;
+    l = (int)lu;
 }
 
 // Lane map of a row tile (RPT = 16 / W image rows per tile): lane l16 of a 16-lane DPP row = column w = l16 / RPT of image row

@@ -37,10 +37,8 @@ constexpr int K_CK = 32, K_LDK = 36;          // channels per chunk; floats per 
 constexpr int K_WAVES = 8, K_NTHR = 512;
 
 __device__ __forceinline__ k_f32x2 ksplit2(float a, float b) {
-    const float xa = a * K_ACT_SCALE, xb = b * K_ACT_SCALE;
-    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
-    const k_f16x2 h = {ha, hb};
-    const k_f16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    unsigned h, l;
+    split_pair_f16(a * K_ACT_SCALE, b * K_ACT_SCALE, h, l);
     return k_f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 

@@ -104,10 +104,8 @@ constexpr int wp_order(int t, int rt, int RT) {       // position of (t, rt) in 
 #endif
 
 __device__ __forceinline__ f32x2 split2(float a, float b) {
-    const float xa = a * ACT_SCALE, xb = b * ACT_SCALE;
-    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
-    const f16x2 h = {ha, hb};
-    const f16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    unsigned h, l;
+    split_pair_f16(a * ACT_SCALE, b * ACT_SCALE, h, l);
     return f32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 

@@ -59,6 +59,21 @@ __device__ __forceinline__ double sum_xor16_f64(double v) {
     return a + b;
 }
 
+// The operand split of every contraction, two values at once, packed: x = hi + lo with hi = fp16(x) (round to nearest)
+// and lo = fp16(x - hi).  v_cvt_pk_f16_f32, two v_fma_mix_f32 (fp16 half * -1 + fp32: x - hi straight from the packed halves, one
+// rounding of an exactly representable difference -- the same bits as x - (float)hi), v_cvt_pk_f16_f32: 4 instructions per pair;
+// the plain C++ form compiles to 6-7 (v_cvt_f32_f16 back and forth).  VALU work is not hidden under the MFMAs on this chip
+// (tools/probes/coexec_probe.hip), so this is time on every launch that converts operands.
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, unsigned& lo) {
+    unsigned h;
+    float la, lb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(h), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(h), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(la), "v"(lb));
+    hi = h;
+}
+
 // Sum of a double over the 64 lanes of a wave, every lane ends with the total: the four in-row steps move the two halves by
 // DPP, rows are joined by v_permlane16_swap / v_permlane32_swap: VALU only.  Fixed order: deterministic.
 __device__ __forceinline__ double wave_sum_f64(double v) {

@@ -54,9 +54,21 @@ struct SaFusedArgs {
     FilmSpec fs;           // fs.on: ... with the coefficients evaluated here (wave 0, film_coef_row_wave) instead of read from ab
 };
 
-__device__ __forceinline__ void sa_split(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
+typedef unsigned s_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 s_f16x2 __attribute__((ext_vector_type(2)));
+// hi / lo fragments of 8 values f(0..7): four split_pair_f16 (device_utils.h: 4 instructions per pair)
+template <typename F>
+__device__ __forceinline__ void sa_split8(s_f16x8& h, s_f16x8& l, F f) {
+    s_u32x4 hu, lu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned a, b;
+        split_pair_f16(f(2 * q), f(2 * q + 1), a, b);
+        hu[q] = a;
+        lu[q] = b;
+    }
+    h = __builtin_bit_cast(s_f16x8, hu);
+    l = __builtin_bit_cast(s_f16x8, lu);
 }
 __device__ __forceinline__ float sa_exp_neg(float x) {
     const float t = x * 1.44269504f;
@@ -68,14 +80,7 @@ __device__ __forceinline__ void sa_make_frags(const s_f32x16 (&z)[2], s_f16x8 (&
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 h, l;
-                sa_split(z[T][8 * s + j] * 16.0f, h, l);
-                bh[2 * T + s][j] = h;
-                bl[2 * T + s][j] = l;
-            }
+        for (int s = 0; s < 2; ++s) sa_split8(bh[2 * T + s], bl[2 * T + s], [&](int j) { return z[T][8 * s + j] * 16.0f; });
 }
 // acc (+)= W[row0 + li][0..63] . B   (one 32-row output tile, K = 64 = 4 k-steps)
 __device__ __forceinline__ s_f32x16 sa_gemm_tile(const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, int row0,
@@ -336,43 +341,38 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
             const int head = 2 * p + sub;
             // registers 8 sub .. 8 sub + 7 are this head's 16 features (8 per lane half, in fragment order)
             s_f16x8 q_h, q_l, k_h, k_l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 h, l;
-                sa_split(qt[8 * sub + j] * 16.0f, h, l);
-                q_h[j] = h; q_l[j] = l;
-                sa_split(kt[8 * sub + j] * 16.0f, h, l);
-                k_h[j] = h; k_l[j] = l;
-            }
+            sa_split8(q_h, q_l, [&](int j) { return qt[8 * sub + j] * 16.0f; });
+            sa_split8(k_h, k_l, [&](int j) { return kt[8 * sub + j] * 16.0f; });
 #ifndef SA_ABLATE_NOKV
             __syncthreads();                        // every wave is done with the previous head's K / V^T
             *reinterpret_cast<s_f16x8*>(Khi + t * SA_KROW + 8 * kh) = k_h;
             *reinterpret_cast<s_f16x8*>(Klo + t * SA_KROW + 8 * kh) = k_l;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {           // V^T[d][token], d = 8 (j>>2) + 4 kh + (j&3)
-                _Float16 h, l;
-                sa_split(vt[8 * sub + j] * 16.0f, h, l);
+            for (int j = 0; j < 8; j += 2) {        // V^T[d][token], d = 8 (j>>2) + 4 kh + (j&3)
+                unsigned hu, lu;
+                split_pair_f16(vt[8 * sub + j] * 16.0f, vt[8 * sub + j + 1] * 16.0f, hu, lu);
+                const s_f16x2 h2 = __builtin_bit_cast(s_f16x2, hu), l2 = __builtin_bit_cast(s_f16x2, lu);
                 const int dd = 8 * (j >> 2) + 4 * kh + (j & 3);
-                Vhi[dd * VROW + tp] = h;
-                Vlo[dd * VROW + tp] = l;
+                Vhi[dd * VROW + tp] = h2[0];
+                Vlo[dd * VROW + tp] = l2[0];
+                Vhi[(dd + 1) * VROW + tp] = h2[1];
+                Vlo[(dd + 1) * VROW + tp] = l2[1];
             }
             if constexpr (PAIR) {
                 s_f16x8 k2_h, k2_l;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    _Float16 h, l;
-                    sa_split(kt2[8 * sub + j] * 16.0f, h, l);
-                    k2_h[j] = h; k2_l[j] = l;
-                }
+                sa_split8(k2_h, k2_l, [&](int j) { return kt2[8 * sub + j] * 16.0f; });
                 *reinterpret_cast<s_f16x8*>(Khi + t2 * SA_KROW + 8 * kh) = k2_h;
                 *reinterpret_cast<s_f16x8*>(Klo + t2 * SA_KROW + 8 * kh) = k2_l;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    _Float16 h, l;
-                    sa_split(vt2[8 * sub + j] * 16.0f, h, l);
+                for (int j = 0; j < 8; j += 2) {
+                    unsigned hu, lu;
+                    split_pair_f16(vt2[8 * sub + j] * 16.0f, vt2[8 * sub + j + 1] * 16.0f, hu, lu);
+                    const s_f16x2 h2 = __builtin_bit_cast(s_f16x2, hu), l2 = __builtin_bit_cast(s_f16x2, lu);
                     const int dd = 8 * (j >> 2) + 4 * kh + (j & 3);
-                    Vhi[dd * VROW + tp2] = h;
-                    Vlo[dd * VROW + tp2] = l;
+                    Vhi[dd * VROW + tp2] = h2[0];
+                    Vlo[dd * VROW + tp2] = l2[0];
+                    Vhi[(dd + 1) * VROW + tp2] = h2[1];
+                    Vlo[(dd + 1) * VROW + tp2] = l2[1];
                 }
             }
             __syncthreads();
@@ -441,12 +441,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     s_f16x8 p_h, p_l;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        _Float16 h, l;
-                        sa_split(sc[8 * s2 + j], h, l);
-                        p_h[j] = h; p_l[j] = l;
-                    }
+                    sa_split8(p_h, p_l, [&](int j) { return sc[8 * s2 + j]; });
                     const s_f16x8 v_h = *reinterpret_cast<const s_f16x8*>(Vhi + li * VROW + kb * 32 + 16 * s2 + 8 * kh);
                     const s_f16x8 v_l = *reinterpret_cast<const s_f16x8*>(Vlo + li * VROW + kb * 32 + 16 * s2 + 8 * kh);
                     acc_o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_h, p_h, acc_o, 0, 0, 0);
@@ -460,12 +455,7 @@ __global__ __launch_bounds__(512, 2) void sa_fused64_kernel(const SaFusedArgs a)
 
             // ---- out-proj: av^T += W_o[:, 16 head .. 16 head + 15] . o_head^T  (one k-step; o rows = registers 0..7) ----
             s_f16x8 o_h, o_l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 h, l;
-                sa_split((acc_o[j] * inv) * 16.0f, h, l);
-                o_h[j] = h; o_l[j] = l;
-            }
+            sa_split8(o_h, o_l, [&](int j) { return (acc_o[j] * inv) * 16.0f; });
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 const s_f16x8 ah = WLDS ? *reinterpret_cast<const s_f16x8*>(Wsh + (192 + 32 * T + li) * SA_WROW + 16 * head + 8 * kh)

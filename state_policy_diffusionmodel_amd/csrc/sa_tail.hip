@@ -56,10 +56,8 @@ struct SaTailArgs {
 };
 
 __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
-    const float xa = a * T_ACT_SCALE, xb = b * T_ACT_SCALE;
-    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
-    const tf16x2 h = {ha, hb};
-    const tf16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    unsigned h, l;
+    split_pair_f16(a * T_ACT_SCALE, b * T_ACT_SCALE, h, l);
     return tf32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
 }
 // sum over the TPR consecutive lanes that hold one row (32: a half-wave; 64: the wave)
@@ -595,14 +593,23 @@ __global__ __launch_bounds__(256, 2) void sa_head_kernel(const SaHeadArgs a) {
                 const int col = cpw * 32 + ct * 16 + l16;                    // column inside the head
                 const float bias = a.b_in[g * T_C + h * D + col];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = rtw * 16 + 4 * kg + j;
-                    float val = acc[ct][j] * T_DESCALE + bias;
-                    if (g == 0) val *= qscale;
-                    const float xs = val * T_ACT_SCALE;
-                    const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
-                    if (g == 2) { Vt[col * VROW + row] = hi; Vt[col * VROW + T_M + row] = lo; }
-                    else { _Float16* X = (g == 0) ? Qs : Ks; X[row * QROW + col] = hi; X[row * QROW + D + col] = lo; }
+                for (int j = 0; j < 4; j += 2) {
+                    float xs[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        float val = acc[ct][j + jj] * T_DESCALE + bias;
+                        if (g == 0) val *= qscale;
+                        xs[jj] = val * T_ACT_SCALE;
+                    }
+                    unsigned hu, lu;
+                    split_pair_f16(xs[0], xs[1], hu, lu);
+                    const tf16x2 h2 = __builtin_bit_cast(tf16x2, hu), l2 = __builtin_bit_cast(tf16x2, lu);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int row = rtw * 16 + 4 * kg + j + jj;
+                        if (g == 2) { Vt[col * VROW + row] = h2[jj]; Vt[col * VROW + T_M + row] = l2[jj]; }
+                        else { _Float16* X = (g == 0) ? Qs : Ks; X[row * QROW + col] = h2[jj]; X[row * QROW + D + col] = l2[jj]; }
+                    }
                 }
             }
         }
@@ -653,11 +660,14 @@ __global__ __launch_bounds__(256, 2) void sa_head_kernel(const SaHeadArgs a) {
                 sum = row16_sum_dpp(sum);
                 const float inv = 1024.0f / sum;
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    const float ps = s[kt] * inv;
-                    const _Float16 hi = (_Float16)ps, lo = (_Float16)(ps - (float)hi);
-                    Ps[row * VROW + kt * 16 + l16] = hi;
-                    Ps[row * VROW + T_M + kt * 16 + l16] = lo;
+                for (int kt = 0; kt < NKT; kt += 2) {          // (NKT = T_M / 16 is even)
+                    unsigned hu, lu;
+                    split_pair_f16(s[kt] * inv, s[kt + 1] * inv, hu, lu);
+                    const tf16x2 h2 = __builtin_bit_cast(tf16x2, hu), l2 = __builtin_bit_cast(tf16x2, lu);
+                    Ps[row * VROW + kt * 16 + l16] = h2[0];
+                    Ps[row * VROW + T_M + kt * 16 + l16] = l2[0];
+                    Ps[row * VROW + (kt + 1) * 16 + l16] = h2[1];
+                    Ps[row * VROW + T_M + (kt + 1) * 16 + l16] = l2[1];
                 }
             }
         }
