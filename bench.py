@@ -434,7 +434,7 @@ def roofline(args, r, split, B, H, D, el, K):
     algo = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = 2516.6 if split else 157.3
     executed = algo * 3.0 if split else algo
-    kernel = ("conv3x3_wide_kernel (3 x v_mfma_f32_16x16x32_f16 per K=32) / conv_gemm_kernel (3 x v_mfma_f32_32x32x16_f16 per K=16): "
+    kernel = ("conv3x3_wide_kernel / conv_reg64_kernel (3 x v_mfma_f32_16x16x32_f16 per K=32) / conv_gemm_kernel (3 x v_mfma_f32_32x32x16_f16 per K=16): "
               "3x3 implicit GEMM, split-fp16 operands, fp32 accumulate" if split
               else "conv_gemm_kernel (3x3 implicit GEMM; v_mfma_f32_32x32x2_f32)")
     traffic = hbm_step = src = None

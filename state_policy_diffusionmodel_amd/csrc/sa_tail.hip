@@ -55,6 +55,16 @@ struct SaTailArgs {
     FilmSpec fs;                                // fs.on: the coefficients are evaluated here, into LDS (ab is null then)
 };
 
+// (plain C++ form: two more instructions per pair, but fewer live registers -- sa_head_kernel sits exactly at the 128-register
+//  line of four waves per SIMD, and the 4-instruction form pushed it over: 238 -> 265 us on sa1 at B = 4096)
+__device__ __forceinline__ tf32x2 tsplit2_plain(float a, float b) {
+    const float xa = a * T_ACT_SCALE, xb = b * T_ACT_SCALE;
+    const _Float16 ha = (_Float16)xa, hb = (_Float16)xb;
+    const tf16x2 h = {ha, hb};
+    const tf16x2 l = {(_Float16)(xa - (float)ha), (_Float16)(xb - (float)hb)};
+    return tf32x2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
+}
+#define TAIL_SPLIT2 tsplit2
 __device__ __forceinline__ tf32x2 tsplit2(float a, float b) {
     unsigned h, l;
     split_pair_f16(a * T_ACT_SCALE, b * T_ACT_SCALE, h, l);
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void sa_tail_kernel(const SaTailArgs a) {
     // slab <- the thread's 8 row pieces v_[i] (fp32), split to fp16 hi / lo
 #define TAIL_WRITE_SLAB(v_)                                                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                             \
-        const tf32x2 p0_ = tsplit2(v_[i_].x, v_[i_].y), p1_ = tsplit2(v_[i_].z, v_[i_].w);           \
+        const tf32x2 p0_ = TAIL_SPLIT2(v_[i_].x, v_[i_].y), p1_ = TAIL_SPLIT2(v_[i_].z, v_[i_].w);   \
         float* rowp_ = Abuf + ((c16 >> 3) * T_M + RPP * i_ + srow0) * T_LDK;                         \
         *reinterpret_cast<tf32x2*>(rowp_ + (c16 & 7) * 2) = tf32x2{p0_.x, p1_.x};                    \
         *reinterpret_cast<tf32x2*>(rowp_ + 16 + (c16 & 7) * 2) = tf32x2{p0_.y, p1_.y};               \
@@ -482,6 +492,8 @@ __device__ __forceinline__ float head_exp_neg(float x) {      // exp(x), x <= 0,
     return __builtin_amdgcn_exp2f(t) * (1.0f + tl * 0.69314718f);
 }
 
+#undef TAIL_SPLIT2
+#define TAIL_SPLIT2 tsplit2_plain
 template <int C>
 __global__ __launch_bounds__(256, 2) void sa_head_kernel(const SaHeadArgs a) {
     using S = TailShape<C>;
@@ -593,23 +605,14 @@ __global__ __launch_bounds__(256, 2) void sa_head_kernel(const SaHeadArgs a) {
                 const int col = cpw * 32 + ct * 16 + l16;                    // column inside the head
                 const float bias = a.b_in[g * T_C + h * D + col];
 #pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    float xs[2];
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        float val = acc[ct][j + jj] * T_DESCALE + bias;
-                        if (g == 0) val *= qscale;
-                        xs[jj] = val * T_ACT_SCALE;
-                    }
-                    unsigned hu, lu;
-                    split_pair_f16(xs[0], xs[1], hu, lu);
-                    const tf16x2 h2 = __builtin_bit_cast(tf16x2, hu), l2 = __builtin_bit_cast(tf16x2, lu);
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int row = rtw * 16 + 4 * kg + j + jj;
-                        if (g == 2) { Vt[col * VROW + row] = h2[jj]; Vt[col * VROW + T_M + row] = l2[jj]; }
-                        else { _Float16* X = (g == 0) ? Qs : Ks; X[row * QROW + col] = h2[jj]; X[row * QROW + D + col] = l2[jj]; }
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int row = rtw * 16 + 4 * kg + j;
+                    float val = acc[ct][j] * T_DESCALE + bias;
+                    if (g == 0) val *= qscale;
+                    const float xs = val * T_ACT_SCALE;
+                    const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
+                    if (g == 2) { Vt[col * VROW + row] = hi; Vt[col * VROW + T_M + row] = lo; }
+                    else { _Float16* X = (g == 0) ? Qs : Ks; X[row * QROW + col] = hi; X[row * QROW + D + col] = lo; }
                 }
             }
         }
@@ -660,14 +663,11 @@ __global__ __launch_bounds__(256, 2) void sa_head_kernel(const SaHeadArgs a) {
                 sum = row16_sum_dpp(sum);
                 const float inv = 1024.0f / sum;
 #pragma unroll
-                for (int kt = 0; kt < NKT; kt += 2) {          // (NKT = T_M / 16 is even)
-                    unsigned hu, lu;
-                    split_pair_f16(s[kt] * inv, s[kt + 1] * inv, hu, lu);
-                    const tf16x2 h2 = __builtin_bit_cast(tf16x2, hu), l2 = __builtin_bit_cast(tf16x2, lu);
-                    Ps[row * VROW + kt * 16 + l16] = h2[0];
-                    Ps[row * VROW + T_M + kt * 16 + l16] = l2[0];
-                    Ps[row * VROW + (kt + 1) * 16 + l16] = h2[1];
-                    Ps[row * VROW + T_M + (kt + 1) * 16 + l16] = l2[1];
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const float ps = s[kt] * inv;
+                    const _Float16 hi = (_Float16)ps, lo = (_Float16)(ps - (float)hi);
+                    Ps[row * VROW + kt * 16 + l16] = hi;
+                    Ps[row * VROW + T_M + kt * 16 + l16] = lo;
                 }
             }
         }

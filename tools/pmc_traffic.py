@@ -31,7 +31,8 @@ def per_kernel(path: str, counter: str):
 
 
 def is_conv3x3(k: str) -> bool:
-    return k.startswith("conv3x3_wide_kernel") or k.startswith("conv_gemm_kernel<true") or k.startswith("conv_skinny_kernel")
+    return (k.startswith("conv3x3_wide_kernel") or k.startswith("conv_gemm_kernel<true") or k.startswith("conv_skinny_kernel") or
+            k.startswith("conv_reg64_kernel"))
 
 
 def main():
@@ -56,7 +57,7 @@ def main():
     steps = max(fetch.get("out_step_kernel", [1, 0])[0], 1)        # one out_step_kernel launch per denoise step
     outp = a.prefix + "_roofline_traffic" + sfx + ".json"
     json.dump({
-        "kernel_class": "conv3x3_wide_kernel<...> + conv_gemm_kernel<HALO=true,...> + conv_skinny_kernel<...> (all 3x3/3x1 implicit-GEMM launches of a denoise step)",
+        "kernel_class": "conv3x3_wide_kernel<...> + conv_reg64_kernel<...> + conv_gemm_kernel<HALO=true,...> + conv_skinny_kernel<...> (all 3x3/3x1 implicit-GEMM launches of a denoise step)",
         "traffic_bytes_per_launch": tot / max(n, 1), "launches_profiled": int(n),
         "hbm_bytes_per_step": all_bytes / steps, "steps_profiled": int(steps),
         "config": {"batch": a.batch, "horizon": a.horizon, "state_dim": a.state_dim, "kind": a.kind, "attention": not a.no_attention},

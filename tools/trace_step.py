@@ -6,9 +6,22 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "conv_in_kernel" in r["Kernel_Name"]]      # first kernel of a denoise step
-step = rows[idx[-1]:]
-end = next((i for i, r in enumerate(step) if "out_step" in r["Kernel_Name"]), len(step) - 1)
-step = step[: end + 1]
+
+
+def step_at(k):
+    st = rows[idx[k]:]
+    end = next((i for i, r in enumerate(st) if "out_step" in r["Kernel_Name"]), len(st) - 1)
+    return st[: end + 1]
+
+
+# the LAST step whose launches are back to back (a step interrupted by the profiler's own buffer flush shows a gap of a millisecond)
+step = step_at(-1)
+for k in range(len(idx) - 1, -1, -1):
+    cand = step_at(k)
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in cand)
+    if int(cand[-1]["End_Timestamp"]) - int(cand[0]["Start_Timestamp"]) <= 1.1 * busy:
+        step = cand
+        break
 tot = 0.0
 agg = {}
 for r in step:
