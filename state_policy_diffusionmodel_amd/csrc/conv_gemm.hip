@@ -966,6 +966,16 @@ static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipSt
             return launch_cfg<false, PREC_SPLIT, 2, 2, 2, 1, 1>(a, g, s);
         }
         if (g.m_tile == 512) return launch_cfg<true, PREC_SPLIT, 8, 1, 2, 2, 3>(a, g, s);
+        // width-2 maps whose 256-row tiling is at most one workgroup per CU: conv_gemm's 8-wave form of the same tile (two waves per
+        // SIMD) instead of conv_wide's 4-wave one (one) -- whole step, same box, alternating: -16 us at B = 1024, -22 us at 512
+        // (SPDM_TUNE20 bit 2 off: the old routing; the same trade for the 128 x 128 tiles of the width-4 level LOSES 14-16 us)
+        // (rows as the geometry was chosen for: a pinned shard must run the kernels of the whole batch)
+        const int gM = a.geom_M > 0 ? a.geom_M : a.M;
+        if ((spdm_tune(20, 7) & 4) && uses_w2(a, g) && g.m_tile == 256 && a.skip == nullptr &&
+            (long long)((gM + 255) / 256) * g.n_tiles * std::max(a.ksplit, 1) <= 256) {
+            if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 2, 3, true>(a, g, s);
+            return launch_cfg<true, PREC_SPLIT, 4, 2, 2, 1, 3, true>(a, g, s);
+        }
         if (conv_wide_supported(a, g)) return launch_conv_wide(a, g, s);          // conv_wide.hip (256- or 128-row tiles)
         if (g.m_tile == 256) {
             if (uses_w2(a, g)) {   // level-2 maps: zero-tap skipping
@@ -977,7 +987,7 @@ static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipSt
         }
         // few workgroups (small batches): the K loop is paced by one weight fetch per iteration, so walk three taps per
         // iteration (3 x the bytes in flight per round trip)
-        const long long wgs = (long long)((a.M + 127) / 128) * g.n_tiles;
+        const long long wgs = (long long)((gM + 127) / 128) * g.n_tiles;
         if (wgs <= 512 && !(a.sw & SW_NO_SMALL_TPI3)) {
             // DEEP (loads two iterations ahead, double-buffered A slab) is an opt-in experiment (SPDM_DEEP=1): measured over all
             // 31 layers at B = 1 / 256 / 512 it changes NOTHING (369 vs 364, 1018 vs 1014, 1440 vs 1441 us of convs per step) --
@@ -985,7 +995,12 @@ static hipError_t launch_gemm_kernel(const GemmArgs& a, const GemmGeom& g, hipSt
             // its CU: ~1150 MFMA cycles + ~1600 cycles of GroupNorm/GELU/split staging + LDS writes and fragment reads per iteration.
             // (64-wide tiles only: with 128-wide tiles two staging sets do not fit 256 registers.)
             if ((a.sw & SW_DEEP) && g.n_tile == 64) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 3, false, true>(a, g, s);
+            // ... on EIGHT waves (32 x 32 per wave) rather than four (64 x 32 / 64 x 64): these grids are at most two workgroups per
+            // CU, so a 4-wave workgroup leaves a SIMD with one or two waves and every round trip exposed.  Whole step, same box,
+            // alternating (tools/probes/ab_switch.sh SPDM_TUNE20=0): -38 us at B = 1024, -41 us at 512, -18 us at 256, -16 us at 64.
+            if (g.n_tile == 128 && (spdm_tune(20, 7) & 2)) return launch_cfg<true, PREC_SPLIT, 4, 2, 1, 2, 3>(a, g, s);
             if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2, 3>(a, g, s);
+            if (spdm_tune(20, 7) & 1) return launch_cfg<true, PREC_SPLIT, 4, 2, 1, 1, 3>(a, g, s);
             return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 1, 3>(a, g, s);
         }
         if (g.n_tile == 128) return launch_cfg<true, PREC_SPLIT, 2, 2, 2, 2, 1>(a, g, s);
