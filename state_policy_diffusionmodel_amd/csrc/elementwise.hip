@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
 }
 
-// row parts per sample: 4 at small batch (Hp is a multiple of 8, so HW / 4 is a multiple of 16 rows), else 1 (every part
-// re-loads the whole padded image: 60 -> 71 us at B = 4096) -- StatsRef{m_tile = HW / parts, n_tiles = 1}
-int conv_in_parts(int Hp, int Wp, int B) { return (B < 256 && (Hp * Wp) % 64 == 0) ? 4 : 1; }
+// row parts per sample: 4 below batch 1024 (Hp is a multiple of 8, so HW / 4 is a multiple of 16 rows; whole step, same box: -7 us at
+// B = 256, -8..-16 us at 512, 0 at 1024), else 1 (every part re-loads the whole padded image: 60 -> 71 us at B = 4096) -- StatsRef{m_tile = HW / parts, n_tiles = 1}
+int conv_in_parts(int Hp, int Wp, int B) { return (B < spdm_tune(21, 1024) && (Hp * Wp) % 64 == 0) ? 4 : 1; }
 
 hipError_t launch_conv_in(const float* x, const float* w, float* dst, double* stats, int B, int H0, int D,
                           int Hp, int Wp, int lh, int lw, int* step_dev, int* t_dev, const int* timesteps, int n_steps,
