@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Phase timeline of conv_reg64_kernel (workgroup 0, waves 0 and 4, first three tiles) on inc.b at batch BG_B (diagnostic build only:
    SPDM_EXTRA_FLAGS=-DSPDM_DIAG_REG SPDM_BUILD_OUT=.../libspdm_reg.so python -m state_policy_diffusionmodel_amd.build).
-usage: SPDM_LIB=.../libspdm_reg.so BG_B=4096 python tools/probes/reg_stamps.py"""
+usage: SPDM_LIB=.../libspdm_reg.so BG_B=4096 python tools/probes/reg_stamps.py
+(The stamps order memory waits exactly -- each ends an s_waitcnt vmcnt(0) lgkmcnt(0) -- but not VALU work: hipcc moves register
+arithmetic across them, so the prologue shows up inside the MFMA phases.  What they showed: the second wave of a SIMD runs 2-3 x
+slower than the first while both are resident, and loads behind the previous tile's stores wait for the write acknowledgements.)"""
 import ctypes
 import os
 import sys
